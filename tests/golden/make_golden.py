@@ -1,0 +1,218 @@
+"""Generates tests/golden/*.npz|*.json from the REFERENCE's own classes.
+
+Runs only in the build container (needs /root/reference); the committed outputs are data, not code.
+Recipe = SURVEY.md section 8(c): the unmodified reference files are exec'd under a synthetic package
+with inert stubs for the modules this image lacks (cv2, torchvision, aiofiles) and the two names the
+files forget to import (Tuple, Optional) pre-seeded.  Nothing is fetched: only classes that construct
+offline are touched (CRNN, DBHead, FeaturePyramidNetwork, TextRecognizer(use_transformer=False) helpers,
+VideoTextPipeline methods through __new__).
+
+Weights come from the build's own deterministic generator (vtd_amd.nets.seeded_state_dict) and are
+loaded into the reference classes with load_state_dict(strict=True), which also pins the key contract.
+
+    python tests/golden/make_golden.py
+"""
+import asyncio
+import importlib.machinery
+import json
+import os
+import sys
+import types
+import typing
+from unittest.mock import Mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "video-text-detection-system_amd"))
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def load_reference():
+    import transformers  # noqa: F401  (must be imported before a torchvision stub exists)
+    from transformers import TrOCRProcessor, VisionEncoderDecoderModel  # noqa: F401
+    _stub("cv2")
+    _stub("aiofiles")
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    for pkg in ("refpkg", "refpkg.models", "refpkg.utils", "refpkg.inference"):
+        m = _stub(pkg)
+        m.__path__ = []
+
+    def run(rel, modname, package, **seed):
+        path = os.path.join(REF, rel)
+        mod = types.ModuleType(modname)
+        mod.__file__ = path
+        mod.__package__ = package
+        mod.__dict__.update(seed)
+        sys.modules[modname] = mod
+        with open(path) as f:
+            exec(compile(f.read(), path, "exec"), mod.__dict__)
+        return mod
+
+    rec = run("app/ml/models/text_recognizer.py", "refpkg.models.text_recognizer", "refpkg.models", Tuple=typing.Tuple)
+    det = run("app/ml/models/text_detector.py", "refpkg.models.text_detector", "refpkg.models")
+    run("app/ml/utils/preprocessing.py", "refpkg.utils.preprocessing", "refpkg.utils", Optional=typing.Optional)
+    pipe = run("app/ml/inference/pipeliine.py", "refpkg.inference.pipeline", "refpkg.inference")
+    return rec, det, pipe
+
+
+def stats(t):
+    t = t.double()
+    return {"sum": float(t.sum()), "abs_sum": float(t.abs().sum()), "sq_sum": float((t * t).sum()),
+            "shape": list(t.shape)}
+
+
+def main():
+    from vtd_amd import nets as mynets
+    rec, det, pipe = load_reference()
+    out = {}
+
+    # ---- G5 vocab, G4 decode quirks (reference TextRecognizer helpers, no model needed)
+    tr = rec.TextRecognizer.__new__(rec.TextRecognizer)
+    tr.vocab = tr._build_vocab()
+    vocab = tr.vocab
+    json.dump({"size": len(vocab), "items": sorted(vocab.items(), key=lambda kv: kv[1])},
+              open(os.path.join(HERE, "vocab.json"), "w"))
+
+    def onehot(seq, T=None, peak=0.9):
+        T = T or len(seq)
+        m = np.full((T, len(vocab)), (1 - peak) / (len(vocab) - 1), np.float32)
+        for t, s in enumerate(seq):
+            m[t, vocab[s] if isinstance(s, str) else s] = peak
+        for t in range(len(seq), T):
+            m[t, 0] = peak
+        return m
+
+    B, U = "<blank>", "<unk>"
+    cases = {
+        "hello": list("hello"), "hel_lo": ["h", "e", "l", B, "l", "o"], "aa_a": ["a", "a", B, "a"],
+        "a_b_a": ["a", B, "b", B, "a"], "a_unk_a": ["a", U, "a"], "all_blank": [B, B, B, B],
+        "spaces": [" ", "A", " ", " ", "~"], "unk_only": [U, U], "digits31": list("0123456789" * 3) + ["0"],
+    }
+    rng = np.random.default_rng(1234)
+    dec_in, dec_out = {}, {}
+    for name, seq in cases.items():
+        m = onehot(seq)
+        # vary the peak per row so the confidence-row quirk (row index = output length-1) is visible
+        for t in range(m.shape[0]):
+            k = m[t].argmax()
+            m[t, k] = 0.5 + 0.4 * rng.random()
+        dec_in[name] = m
+    for i in range(6):  # random softmax rows, T=31 and the test-suite's T=10
+        T = 31 if i < 3 else 10
+        z = rng.standard_normal((T, len(vocab))).astype(np.float32) * 3
+        e = np.exp(z - z.max(1, keepdims=True))
+        dec_in[f"rand{i}"] = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    for name, m in dec_in.items():
+        t, c = tr._decode_prediction(torch.from_numpy(m))
+        dec_out[name] = {"text": t, "confidence": c}
+    np.savez_compressed(os.path.join(HERE, "decode_inputs.npz"), **dec_in)
+    json.dump(dec_out, open(os.path.join(HERE, "decode_expected.json"), "w"), indent=1)
+
+    # ---- G1 CRNN logits + conv-stack tap
+    sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    ref_crnn = rec.CRNN(97).eval()
+    ref_crnn.load_state_dict(sd, strict=True)
+    out["crnn_keys"] = {k: list(v.shape) for k, v in ref_crnn.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(4, 3, 32, 128, generator=g)
+    with torch.no_grad():
+        logits = ref_crnn(x)
+        feat = ref_crnn.cnn(x[:1])
+    np.savez_compressed(os.path.join(HERE, "crnn_g1.npz"), logits=logits.numpy(), cnn_b0=feat.numpy())
+    out["crnn_g1"] = {"weights_seed": 11, "input_seed": 21, "input": "torch.rand(4,3,32,128, generator=manual_seed(21))",
+                      "logits": stats(logits), "cnn": stats(feat)}
+
+    # ---- G2 DBHead probability branch
+    head_sd = mynets.seeded_state_dict(lambda: mynets.DBHead(256), seed=12)
+    ref_head = det.DBHead(256).eval()
+    ref_head.load_state_dict(head_sd, strict=True)
+    out["dbhead_keys"] = {k: list(v.shape) for k, v in ref_head.state_dict().items()}
+    g = torch.Generator().manual_seed(22)
+    xs = torch.randn(1, 256, 16, 16, generator=g)
+    xl = torch.randn(1, 256, 160, 160, generator=g)
+    with torch.no_grad():
+        ps = ref_head(xs)
+        pl = ref_head(xl)
+    np.savez_compressed(os.path.join(HERE, "dbhead_g2.npz"), prob_small=ps["probability"].numpy(),
+                        thresh_small=ps["threshold"].numpy(),
+                        prob_large_corner=pl["probability"][0, 0, :64, :64].numpy(),
+                        prob_large_center=pl["probability"][0, 0, 288:352, 288:352].numpy())
+    out["dbhead_g2"] = {"weights_seed": 12, "input_seed": 22,
+                        "input": "g=manual_seed(22); randn(1,256,16,16,g) then randn(1,256,160,160,g)",
+                        "prob_small": stats(ps["probability"]), "prob_large": stats(pl["probability"])}
+
+    # ---- G3 FPN sub-modules wired as intended, both channel plans, base 4
+    for cin, tag in ((2048, "r50"), (512, "r18")):
+        fsd = mynets.seeded_state_dict(lambda: mynets.FeaturePyramidNetwork(cin), seed=13)
+        ref_fpn = det.FeaturePyramidNetwork(cin).eval()
+        ref_fpn.load_state_dict(fsd, strict=True)
+        out[f"fpn_keys_{tag}"] = {k: list(v.shape) for k, v in ref_fpn.state_dict().items()}
+        g = torch.Generator().manual_seed(23)
+        feats = [torch.randn(1, cin >> i, 4 << i, 4 << i, generator=g) for i in range(4)]  # C5,C4,C3,C2
+        with torch.no_grad():
+            last = ref_fpn.inner_blocks[0](feats[0])
+            for i in range(1, 4):
+                last = ref_fpn.inner_blocks[i](feats[i]) + torch.nn.functional.interpolate(last, scale_factor=2, mode="nearest")
+            p2 = ref_fpn.layer_blocks[3](last)
+        np.savez_compressed(os.path.join(HERE, f"fpn_g3_{tag}.npz"), p2_first16=p2[0, :16].numpy())
+        out[f"fpn_g3_{tag}"] = {"weights_seed": 13, "input_seed": 23,
+                                "input": "g=manual_seed(23); [randn(1,cin>>i,4<<i,4<<i,g) for i in 0..3] = C5,C4,C3,C2",
+                                "p2": stats(p2)}
+
+    # ---- H1-H3 pipeline harness rows through the reference's own VideoTextPipeline methods
+    P = pipe.VideoTextPipeline
+    p = P.__new__(P)
+    p.confidence_threshold = 0.5
+    p.batch_size = 16
+    from concurrent.futures import ThreadPoolExecutor
+    p.executor = ThreadPoolExecutor(max_workers=4)
+    p.detector = Mock()
+    p.recognizer = Mock()
+    dets = [{"bbox": [50, 80, 200, 120], "confidence": 0.8, "polygon": [[50, 80], [200, 80], [200, 120], [50, 120]]},
+            {"bbox": [10, 10, 10, 40], "confidence": 0.7}]
+    p.detector.detect.return_value = dets
+    p.recognizer.recognize.return_value = {"text": " TEST TEXT ", "confidence": 0.9}
+    frame = np.zeros((480, 640, 3), np.uint8)
+    h1 = p.process_single_frame(frame)
+    crop_shape = list(p.recognizer.recognize.call_args[0][0].shape)
+    h2 = asyncio.run(p._process_frame_batch([frame, frame], [(0, 0.0), (1, 0.1)], "/tmp"))
+    p.detector.detect.return_value = [{"bbox": [50, 80, 200, 120], "confidence": 0.8}]
+    h2b = asyncio.run(p._process_frame_batch([frame], [(5, 0.5)], "/tmp"))
+    p.detector.detect.return_value = []
+    h2c = asyncio.run(p._process_frame_batch([frame], [(6, 0.6)], "/tmp"))
+    p.detector.detect.side_effect = Exception("boom")
+    h1err = p.process_single_frame(frame)
+    results = [
+        {"frame_number": 0, "timestamp": 0.0, "detections": [
+            {"text": " A ", "detection_confidence": 0.5, "recognition_confidence": 1.0}]},
+        {"frame_number": 1, "timestamp": 0.1, "detections": []},
+        {"frame_number": 2, "timestamp": 0.2, "detections": [
+            {"text": "A", "detection_confidence": 1.0, "recognition_confidence": 0.5},
+            {"text": "  ", "detection_confidence": 0.0, "recognition_confidence": 0.0}]},
+    ]
+    h3 = p._generate_summary(results, 2.0, 3)
+    h3empty = p._generate_summary([], 0.0, 0)
+    json.dump({"H1": h1, "H1_crop_shape": crop_shape, "H1_error": h1err, "H2": h2, "H2_no_polygon": h2b,
+               "H2_no_detections": h2c, "H3_input": results, "H3": h3, "H3_empty": h3empty},
+              open(os.path.join(HERE, "pipeline_harness.json"), "w"), indent=1)
+
+    json.dump(out, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

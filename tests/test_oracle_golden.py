@@ -1,0 +1,122 @@
+"""Pins the CPU oracle against vectors produced by the reference's own classes
+(tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import nets as onets
+from oracle import pipeline as opipe
+from vtd_amd import nets as mynets
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _manifest(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "manifest.json")))
+
+
+def test_g5_vocab(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "vocab.json")))
+    v = opipe.build_vocab()
+    assert len(v) == g["size"] == 97
+    assert sorted(v.items(), key=lambda kv: kv[1]) == [tuple(x) for x in g["items"]]
+    assert (v["0"], v["a"], v["A"], v["~"], v[" "], v["<blank>"], v["<unk>"]) == (1, 11, 37, 94, 95, 0, 96)
+    # the product's table is the same object contract
+    from vtd_amd.vocab import build_vocab
+    assert build_vocab() == v
+
+
+def test_g4_decode_quirks(golden_dir):
+    inputs = _load(golden_dir, "decode_inputs.npz")
+    expected = json.load(open(os.path.join(golden_dir, "decode_expected.json")))
+    assert expected["hello"]["text"] == "helo" and expected["a_unk_a"]["text"] == "aa"
+    for name, exp in expected.items():
+        text, conf = opipe.decode_prediction(inputs[name])
+        assert text == exp["text"], name
+        assert abs(conf - exp["confidence"]) <= 1e-7, name
+
+
+def test_state_dict_key_contract(golden_dir):
+    m = _manifest(golden_dir)
+    assert {k: list(v.shape) for k, v in mynets.CRNN(97).state_dict().items()} == m["crnn_keys"]
+    assert {k: list(v.shape) for k, v in mynets.DBHead(256).state_dict().items()} == m["dbhead_keys"]
+    assert {k: list(v.shape) for k, v in mynets.FeaturePyramidNetwork(2048).state_dict().items()} == m["fpn_keys_r50"]
+    assert {k: list(v.shape) for k, v in mynets.FeaturePyramidNetwork(512).state_dict().items()} == m["fpn_keys_r18"]
+    assert len(m["crnn_keys"]) == 67  # 67 tensors (incl. 7 num_batches_tracked)
+    assert sum(int(np.prod(s)) for k, s in m["crnn_keys"].items() if "num_batches" not in k and "running" not in k) == 8758113
+
+
+def test_g1_crnn_logits(golden_dir):
+    g = _load(golden_dir, "crnn_g1.npz")
+    sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    x = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(21))
+    logits, feat = onets.crnn_forward(x, sd, return_cnn=True)
+    assert logits.shape == (4, 31, 97) and feat.shape == (4, 512, 1, 31)
+    np.testing.assert_allclose(feat[:1].numpy(), g["cnn_b0"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-5)
+    # batch-size independence of the restatement (B=1 slice of the same inputs)
+    np.testing.assert_allclose(onets.crnn_forward(x[2:3], sd).numpy(), g["logits"][2:3], rtol=0, atol=2e-5)
+
+
+def test_g2_dbhead(golden_dir):
+    g = _load(golden_dir, "dbhead_g2.npz")
+    m = _manifest(golden_dir)["dbhead_g2"]
+    sd = mynets.seeded_state_dict(lambda: mynets.DBHead(256), seed=12)
+    gen = torch.Generator().manual_seed(22)
+    xs = torch.randn(1, 256, 16, 16, generator=gen)
+    xl = torch.randn(1, 256, 160, 160, generator=gen)
+    with torch.no_grad():
+        ps = onets.db_branch(xs, sd, "probability_head.")
+        ts = onets.db_branch(xs, sd, "threshold_head.")
+        pl = onets.db_branch(xl, sd, "probability_head.")
+    assert pl.shape == (1, 1, 640, 640)
+    np.testing.assert_allclose(ps.numpy(), g["prob_small"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ts.numpy(), g["thresh_small"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pl[0, 0, :64, :64].numpy(), g["prob_large_corner"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pl[0, 0, 288:352, 288:352].numpy(), g["prob_large_center"], rtol=0, atol=1e-6)
+    assert abs(float(pl.double().sum()) - m["prob_large"]["sum"]) <= 1e-6 * m["prob_large"]["abs_sum"]
+
+
+def test_g3_fpn_intended_wiring(golden_dir):
+    man = _manifest(golden_dir)
+    for cin, tag in ((2048, "r50"), (512, "r18")):
+        g = _load(golden_dir, f"fpn_g3_{tag}.npz")
+        sd = mynets.seeded_state_dict(lambda: mynets.FeaturePyramidNetwork(cin), seed=13)
+        sd = {"fpn." + k: v for k, v in sd.items()}
+        gen = torch.Generator().manual_seed(23)
+        c5, c4, c3, c2 = [torch.randn(1, cin >> i, 4 << i, 4 << i, generator=gen) for i in range(4)]
+        with torch.no_grad():
+            p2 = onets.fpn_forward([c2, c3, c4, c5], sd)
+        assert p2.shape == (1, 256, 32, 32)
+        np.testing.assert_allclose(p2[0, :16].numpy(), g["p2_first16"], rtol=0, atol=2e-5)
+        s = man[f"fpn_g3_{tag}"]["p2"]
+        assert abs(float(p2.double().sum()) - s["sum"]) <= 1e-5 * s["abs_sum"]
+
+
+def test_h3_summary(golden_dir):
+    h = json.load(open(os.path.join(golden_dir, "pipeline_harness.json")))
+    got = opipe.generate_summary(h["H3_input"], 2.0, 3)
+    exp = dict(h["H3"])
+    assert set(got.pop("detected_texts")) == set(exp.pop("detected_texts"))
+    assert got == exp
+    got = opipe.generate_summary([], 0.0, 0)
+    assert got == h["H3_empty"]
+
+
+def test_dbnet_restatement_shapes_and_dead_branches():
+    """Trunk is PARITY UNPINNED (torchvision absent): check the shape contract SURVEY section 0 derives
+    (C2..C5 channels/strides, 640x640 map) on a reduced input, for both channel plans."""
+    for backbone, chans in (("resnet18", (64, 128, 256, 512)), ("resnet50", (256, 512, 1024, 2048))):
+        sd = mynets.seeded_state_dict(lambda: mynets.DBNet(backbone), seed=5)
+        x = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+        out = onets.dbnet_forward(x, sd, backbone, return_taps=True)
+        assert [t.shape[1] for t in out["taps"]] == list(chans)
+        assert [t.shape[2] for t in out["taps"]] == [16, 8, 4, 2]
+        assert out["p2"].shape == (1, 256, 16, 16)
+        assert out["probability"].shape == (1, 1, 64, 64)
+        assert out["threshold"] is None
+        assert 0.0 < float(out["probability"].min()) and float(out["probability"].max()) < 1.0
