@@ -1,0 +1,79 @@
+/*
+ * vtd.h -- C ABI of libvtd_hip.so, the MI355X (gfx950) implementation of the per-frame
+ * text-detection / recognition hot path of malak29/video-text-detection-system.
+ *
+ * The reference has no FFI for this path: its boundary is the Python class API of app/ml
+ * (TextDetector / TextRecognizer / VideoTextPipeline).  The entry points below are what a binding
+ * for those classes needs; each cites the reference interface it replaces (file:line relative to the
+ * reference repository).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, opaque handles, caller-owned device buffers, no torch / C++ types in signatures
+ *   - every call returns 0 on success, a negative value on failure: -(hipError_t) for HIP errors,
+ *     -1000 and below for argument / shape validation errors; vtd_strerror() names them
+ *   - every launching call takes the HIP stream to enqueue on (pass NULL for the default stream);
+ *     nothing synchronises the device unless documented
+ *   - no process-global state: N handles (one per GPU / per worker thread) coexist; a handle must be
+ *     used from one stream at a time
+ *   - "dev" pointers are device memory on the handle's device; "host" pointers are host memory
+ */
+#ifndef VTD_H
+#define VTD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vtd_detector vtd_detector;
+typedef struct vtd_recognizer vtd_recognizer;
+typedef struct vtd_postproc vtd_postproc;
+typedef void* vtd_stream; /* hipStream_t */
+
+/* One detection, as TextDetector._post_process emits it (app/ml/models/text_detector.py:172-176):
+ * bbox in frame pixels, polygon (4 x (x,y)) in map space, confidence = mean probability. */
+typedef struct vtd_detection {
+    int32_t bbox[4];
+    int32_t polygon[8];
+    float confidence;
+    float area;            /* contour area of the component (diagnostic) */
+    int32_t first_x, first_y; /* raster-first pixel of the component (diagnostic / ordering) */
+} vtd_detection;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+const char* vtd_version(void);
+const char* vtd_strerror(int code);
+/* number of visible HIP devices, or a negative error */
+int vtd_device_count(void);
+
+/* ---- detector: DBNet (text_detector.py:12-86) -------------------------------------------------- */
+/* backbone: "resnet18" | "resnet50" (text_detector.py:16-20; 'resnet18' is the documented repair A2).
+ * max_batch frames of 640x640 network input are provisioned in HBM at creation. */
+int vtd_detector_create(const char* backbone, int max_batch, vtd_detector** out);
+void vtd_detector_destroy(vtd_detector* d);
+/* Feed one tensor of the reference checkpoint's model_state_dict (text_detector.py:108-109) by its key,
+ * e.g. "backbone.0.weight", "fpn.inner_blocks.2.bias", "head.probability_head.3.weight"; float32,
+ * PyTorch memory order.  Unknown keys are rejected, "num_batches_tracked" keys are accepted and ignored. */
+int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_data, int64_t numel);
+/* Folds BatchNorm, repacks to the kernels' fp16 layouts and uploads.  Fails (-1103) if a key is missing. */
+int vtd_detector_finalize(vtd_detector* d, vtd_stream stream);
+/* K1 = cvtColor(BGR2RGB) + ToPILImage + Resize((640,640)) + ToTensor + Normalize (text_detector.py:99-104,
+ * 119-124) for n frames of identical size: frames_dev is [n,H,W,3] uint8 BGR.  Fills the network input. */
+int vtd_detector_preprocess(vtd_detector* d, const uint8_t* frames_dev, int n, int height, int width, vtd_stream stream);
+/* Alternative input: the tensor the reference hands to DBNet.forward, [n,3,640,640] float32 (text_detector.py:124). */
+int vtd_detector_set_input_nchw(vtd_detector* d, const float* x_dev, int n, vtd_stream stream);
+/* DBNet.forward (text_detector.py:25-29) on the current input: prob_dev receives [n,640,640] float32
+ * probabilities (the 'probability' map); thresh_dev, if not NULL, the 'threshold' map. */
+int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_dev, vtd_stream stream);
+/* Debug / test taps: copies an internal activation as dense NCHW float32 to host.  name: "input", "c2".."c5",
+ * "p2", "stem", "head1", "head2".  Synchronises the stream. */
+int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_out, int64_t capacity, vtd_stream stream);
+/* Algorithmic live work of one frame through this detector, in MACs (for roofline accounting). */
+int64_t vtd_detector_macs_per_frame(const vtd_detector* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTD_H */

@@ -1,0 +1,99 @@
+"""GPU parity: HIP preprocess + DBNet (fp16 MFMA) against the fp32 CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import pipeline as opipe
+from vtd_amd import nets as mynets
+from vtd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def r18(hip):
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    eng = DetectorEngine("resnet18", sd, max_batch=4)
+    yield eng, sd
+    eng.close()
+
+
+@pytest.mark.parametrize("shape", [(720, 1280), (1080, 1920), (480, 640), (640, 640), (333, 517)])
+def test_preprocess_bit_exact(r18, shape):
+    """K1: integer resample bit-exact, normalisation identical after fp16 rounding."""
+    from vtd_amd.engine import DeviceFrames
+    eng, _ = r18
+    frames = synth.random_frames(shape[0], 2, *shape)
+    frames[1] = synth.text_frame(3, *shape)[0]
+    with eng.lock:
+        eng._set_input(DeviceFrames(frames))
+    got = eng.read_tap("input", 2)
+    for i in range(2):
+        ref = opipe.preprocess(frames[i])[0].numpy().astype(np.float16).astype(np.float32)
+        assert np.array_equal(got[i], ref), f"frame {i}: {np.abs(got[i] - ref).max()}"
+
+
+def test_dbnet_r18_taps_and_probability(r18):
+    """Tensor-level tolerance test with seeded default-init weights: fp16 activations with
+    fp32 accumulation against the fp32 oracle.  Tolerances: taps 1.5e-2 of the tap's max magnitude,
+    probabilities max|dp| <= 2e-3."""
+    eng, sd = r18
+    x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(9))
+    out = eng.forward(x)
+    torch.cuda.synchronize()
+    ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
+    stem_ref = torch.relu(onets._bn(torch.nn.functional.conv2d(x, sd["backbone.0.weight"], None, 2, 3), sd, "backbone.1"))
+    errs = {"stem": _rel(eng.read_tap("stem", 2), stem_ref.numpy())}
+    for i, name in enumerate(("c2", "c3", "c4", "c5")):
+        errs[name] = _rel(eng.read_tap(name, 2), ref["taps"][i].numpy())
+    errs["p2"] = _rel(eng.read_tap("p2", 2), ref["p2"].numpy())
+    prob = out["probability"].cpu().numpy()
+    dp = float(np.abs(prob - ref["probability"].numpy()).max())
+    print("relative tap errors", errs, "max|dp|", dp)
+    for k, v in errs.items():
+        assert v < 1.5e-2, (k, v)
+    assert prob.shape == (2, 1, 640, 640)
+    assert dp <= 2e-3
+    band = float((np.abs(ref["probability"].numpy() - 0.5) < 2e-3).mean())
+    print("may-flip band fraction at thr=0.5:", band)
+
+
+def test_dbnet_batch_independence_and_threshold_branch(r18):
+    eng, sd = r18
+    x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(10))
+    full = eng.forward(x, want_threshold=True)
+    one = eng.forward(x[1:2])
+    torch.cuda.synchronize()
+    assert torch.equal(full["probability"][1], one["probability"][0])
+    ref = onets.dbnet_forward(x[:1], sd, "resnet18", want_threshold=True)
+    assert float((full["threshold"][0].cpu() - ref["threshold"][0]).abs().max()) <= 2e-3
+
+
+def test_dbnet_r50(hip):
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet50"), seed=6)
+    eng = DetectorEngine("resnet50", sd, max_batch=2)
+    try:
+        x = torch.randn(1, 3, 640, 640, generator=torch.Generator().manual_seed(11))
+        prob = eng.forward(x)["probability"].cpu()
+        ref = onets.dbnet_forward(x, sd, "resnet50", return_taps=True)
+        errs = {n: _rel(eng.read_tap(n, 1), ref["taps"][i].numpy()) for i, n in enumerate(("c2", "c3", "c4", "c5"))}
+        print("r50 tap errors", errs)
+        assert all(v < 2e-2 for v in errs.values()), errs
+        assert float((prob - ref["probability"]).abs().max()) <= 2e-3
+        assert eng.macs_per_frame == pytest.approx(55.83e9, rel=0.01)
+    finally:
+        eng.close()
+
+
+def test_macs_accounting(r18):
+    eng, _ = r18
+    assert eng.macs_per_frame == pytest.approx(34.91e9, rel=0.01)  # 69.8 GFLOP / frame

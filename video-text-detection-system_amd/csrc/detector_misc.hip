@@ -1,0 +1,232 @@
+// HBM-bound detector stages for gfx950: fused frame preprocess (K1), NCHW->internal conversion,
+// stem max-pool, and the final ConvTranspose(64->1)+sigmoid of the DB head.
+#include "vtd_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// K1: BGR uint8 HWC frame -> RGB, Pillow antialiased-bilinear resize to 640x640 (horizontal pass to a
+// uint8 intermediate, then vertical -- bit-exact integer arithmetic), /255, (x-mean)/std, fp16 NHWC4
+// into the ring-3 network input.  Replaces cv2.cvtColor + ToPILImage/Resize/ToTensor/Normalize
+// (app/ml/models/text_detector.py:99-104,119-124).
+//
+// One workgroup = TY output rows of one frame.  Phase 1 resamples the input rows those output rows
+// touch horizontally into LDS (coalesced row reads, each input row is read by at most two workgroups);
+// phase 2 runs the vertical taps out of LDS and writes 8-byte pixels.
+// ------------------------------------------------------------------------------------------------
+constexpr int PRE_TY = 16;
+constexpr int PRE_OUT = 640;
+
+struct PreParams {
+    const uint8_t* frames;  // [n, H, W, 3]
+    half_t* out;            // [n, 646, 646, 4]
+    const int* xb;          // [640][2] xmin, count
+    const int* xk;          // [640][ksx]
+    const int* yb;          // [640][2]
+    const int* yk;          // [640][ksy]
+    int H, W, ksx, ksy;
+    int max_rows;           // LDS rows reserved per workgroup
+};
+
+__device__ __forceinline__ uint8_t clip8_22(int v) {
+    v >>= 22;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];  // [max_rows][640*3]
+    const int oy0 = blockIdx.x * PRE_TY;
+    const int img = blockIdx.y;
+    const int y_first = p.yb[2 * oy0];
+    const int oy_last = min(oy0 + PRE_TY, PRE_OUT) - 1;
+    const int y_end = p.yb[2 * oy_last] + p.yb[2 * oy_last + 1];
+    const int nrows = y_end - y_first;
+    const uint8_t* src = p.frames + (int64_t)img * p.H * p.W * 3;
+
+    // phase 1: horizontal taps, one (row, ox) per thread-iteration, 3 channels each
+    for (int idx = threadIdx.x; idx < nrows * PRE_OUT; idx += 256) {
+        const int ry = idx / PRE_OUT, ox = idx - ry * PRE_OUT;
+        const uint8_t* row = src + (int64_t)(y_first + ry) * p.W * 3;
+        const int xmin = p.xb[2 * ox], cnt = p.xb[2 * ox + 1];
+        const int* k = p.xk + ox * p.ksx;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int t = 0; t < cnt; ++t) {
+            const int kv = k[t];
+            const uint8_t* px = row + (xmin + t) * 3;
+            s0 += px[0] * kv;
+            s1 += px[1] * kv;
+            s2 += px[2] * kv;
+        }
+        uint8_t* d = rows + (ry * PRE_OUT + ox) * 3;
+        d[0] = clip8_22(s0);
+        d[1] = clip8_22(s1);
+        d[2] = clip8_22(s2);
+    }
+    __syncthreads();
+
+    // phase 2: vertical taps + normalise; input channel order is BGR, output RGB0
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int idx = threadIdx.x; idx < PRE_TY * PRE_OUT; idx += 256) {
+        const int ty = idx / PRE_OUT, ox = idx - ty * PRE_OUT;
+        const int oy = oy0 + ty;
+        if (oy >= PRE_OUT) break;
+        const int ymin = p.yb[2 * oy] - y_first, cnt = p.yb[2 * oy + 1];
+        const int* k = p.yk + oy * p.ksy;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int t = 0; t < cnt; ++t) {
+            const int kv = k[t];
+            const uint8_t* px = rows + ((ymin + t) * PRE_OUT + ox) * 3;
+            s0 += px[0] * kv;
+            s1 += px[1] * kv;
+            s2 += px[2] * kv;
+        }
+        const float b = (float)clip8_22(s0), g = (float)clip8_22(s1), r = (float)clip8_22(s2);
+        half4 o;
+        o[0] = (half_t)((r / 255.0f - mean[0]) / stdv[0]);
+        o[1] = (half_t)((g / 255.0f - mean[1]) / stdv[1]);
+        o[2] = (half_t)((b / 255.0f - mean[2]) / stdv[2]);
+        o[3] = (half_t)0.f;
+        *(half4*)(p.out + (((int64_t)img * 646 + oy + 3) * 646 + ox + 3) * 4) = o;
+    }
+}
+
+// Reference-format network input ([n,3,640,640] float32, already normalised) -> ring-3 NHWC4 fp16.
+__global__ void nchw_to_input_kernel(const float* __restrict__ x, half_t* __restrict__ out, int n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * 640 * 640;
+    if (idx >= total) return;
+    const int img = (int)(idx / (640 * 640));
+    const int rem = (int)(idx - (int64_t)img * 640 * 640);
+    const int y = rem / 640, xx = rem - y * 640;
+    const float* base = x + (int64_t)img * 3 * 640 * 640 + rem;
+    half4 o = {(half_t)base[0], (half_t)base[640 * 640], (half_t)base[2 * 640 * 640], (half_t)0.f};
+    *(half4*)(out + (((int64_t)img * 646 + y + 3) * 646 + xx + 3) * 4) = o;
+}
+
+// Generic max-pool over ring-padded NHWC fp16, 8 channels (16 bytes) per thread.  Inputs are post-ReLU
+// (>= 0) so the zero ring is equivalent to -inf padding (every window holds a real pixel).
+struct PoolParams {
+    const half_t* in;
+    half_t* out;
+    int n, c, ho, wo;
+    int in_hp, in_wp, in_y0, in_x0;  // in_y0 = ring_in - pad
+    int out_hp, out_wp, out_ring;
+    int kh, kw, sh, sw;
+};
+
+__global__ void maxpool_kernel(const PoolParams p) {
+    const int cg = p.c >> 3;
+    const int64_t total = (int64_t)p.n * p.ho * p.wo * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int ox = (int)(t % p.wo);
+        t /= p.wo;
+        const int oy = (int)(t % p.ho);
+        const int img = (int)(t / p.ho);
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)(-65504.f);
+        for (int r = 0; r < p.kh; ++r)
+            for (int s = 0; s < p.kw; ++s) {
+                const half8 v = *(const half8*)(p.in + (((int64_t)img * p.in_hp + oy * p.sh + p.in_y0 + r) * p.in_wp +
+                                                         ox * p.sw + p.in_x0 + s) * p.c + g * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        *(half8*)(p.out + (((int64_t)img * p.out_hp + oy + p.out_ring) * p.out_wp + ox + p.out_ring) * p.c + g * 8) = m;
+    }
+}
+
+// Final head stage: ConvTranspose2d(64 -> 1, k=2, s=2) + sigmoid (text_detector.py:68-69).
+// N = 4 outputs per input pixel -> bandwidth bound: 8 lanes share one pixel (16 B each, one 128-B line),
+// partial dot products are combined with wave shuffles, lane 0 of the group writes the 2x2 fp32 block.
+struct FinalParams {
+    const half_t* in;   // [n, 322, 322, 64] ring 1
+    const float* w;     // [4][64]  (ky*2+kx major)
+    float bias;
+    float* prob;        // [n, 640, 640]
+    int n, h, w_in, in_hp, in_wp, ring;
+};
+
+__global__ __launch_bounds__(256) void final_convt_sigmoid_kernel(const FinalParams p) {
+    const int sub = threadIdx.x & 7;
+    float wr[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[o][e] = p.w[o * 64 + sub * 8 + e];
+    const int64_t total = (int64_t)p.n * p.h * p.w_in;
+    for (int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; pix < total;
+         pix += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int img = (int)(pix / (p.h * p.w_in));
+        const int rem = (int)(pix - (int64_t)img * p.h * p.w_in);
+        const int y = rem / p.w_in, x = rem - y * p.w_in;
+        const half8 v = *(const half8*)(p.in + (((int64_t)img * p.in_hp + y + p.ring) * p.in_wp + x + p.ring) * 64 + sub * 8);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] += f * wr[o][e];
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o] += __shfl_xor(acc[o], 1);
+            acc[o] += __shfl_xor(acc[o], 2);
+            acc[o] += __shfl_xor(acc[o], 4);
+        }
+        if (sub == 0) {
+            float* o0 = p.prob + ((int64_t)img * 640 + 2 * y) * 640 + 2 * x;
+            float s[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) s[o] = 1.f / (1.f + __expf(-(acc[o] + p.bias)));
+            *(float2*)o0 = make_float2(s[0], s[1]);
+            *(float2*)(o0 + 640) = make_float2(s[2], s[3]);
+        }
+    }
+}
+
+}  // namespace
+
+int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
+                          const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream) {
+    PreParams p{frames, out, xb, xk, yb, yk, H, W, ksx, ksy, max_rows};
+    const int lds = max_rows * PRE_OUT * 3;
+    if (lds > 160 * 1024) return -1010;
+    static bool attr_done = false;
+    if (!attr_done) {
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)preprocess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(preprocess_kernel, dim3(PRE_OUT / PRE_TY, n), dim3(256), lds, stream, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_nchw_to_input(const float* x, half_t* out, int n, hipStream_t stream) {
+    const int64_t total = (int64_t)n * 640 * 640;
+    hipLaunchKernelGGL(nchw_to_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, out, n);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int kh, int kw, int sh, int sw, int pad_h, int pad_w,
+                       hipStream_t stream) {
+    if (in.c != out.c || (in.c & 7)) return -1020;
+    if (in.ring < pad_h || in.ring < pad_w) return -1021;
+    if ((out.h - 1) * sh - pad_h + kh > in.h + (in.hp - in.h - in.ring) || (out.w - 1) * sw - pad_w + kw > in.w + (in.wp - in.w - in.ring))
+        return -1022;
+    PoolParams p{in.ptr, out.ptr, n, in.c, out.h, out.w, in.hp, in.wp, in.ring - pad_h, in.ring - pad_w,
+                 out.hp, out.wp, out.ring, kh, kw, sh, sw};
+    const int64_t total = (int64_t)n * out.h * out.w * (in.c >> 3);
+    const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream) {
+    if (in.c != 64 || in.h != 320 || in.w != 320) return -1030;
+    FinalParams p{in.ptr, w4x64, bias, prob, n, in.h, in.w, in.hp, in.wp, in.ring};
+    hipLaunchKernelGGL(final_convt_sigmoid_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+    return -(int)hipGetLastError();
+}

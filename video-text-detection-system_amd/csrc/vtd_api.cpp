@@ -1,0 +1,656 @@
+// Host side of libvtd_hip.so: handles, checkpoint ingest (BatchNorm folding + fp16 repack), network
+// graphs, workspace provisioning and the extern "C" entry points declared in include/vtd.h.
+// Compiled with hipcc for gfx950; launches the kernels in conv_igemm.hip / detector_misc.hip / ...
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/vtd.h"
+#include "vtd_common.h"
+
+// kernel launchers (defined in the .hip files)
+int vtd_launch_conv(const ConvParams& p, hipStream_t stream);
+int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
+                          const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream);
+int vtd_launch_nchw_to_input(const float* x, half_t* out, int n, hipStream_t stream);
+int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int kh, int kw, int sh, int sw, int pad_h, int pad_w,
+                       hipStream_t stream);
+int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
+
+namespace vtd {
+
+enum : int {
+    ERR_ARG = -1100,
+    ERR_UNKNOWN_KEY = -1101,
+    ERR_SHAPE = -1102,
+    ERR_MISSING_KEY = -1103,
+    ERR_NOT_FINALIZED = -1104,
+    ERR_BATCH = -1105,
+    ERR_GEOMETRY = -1106,
+    ERR_CAPACITY = -1107,
+};
+
+using StateDict = std::map<std::string, std::vector<float>>;
+
+struct DeviceArena {
+    std::vector<void*> blocks;
+    size_t total = 0;
+    int alloc(void** out, size_t bytes, bool zero) {
+        void* p = nullptr;
+        bytes = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return -(int)e;
+        if (zero) {
+            e = hipMemset(p, 0, bytes);
+            if (e != hipSuccess) return -(int)e;
+        }
+        blocks.push_back(p);
+        total += bytes;
+        *out = p;
+        return 0;
+    }
+    ~DeviceArena() {
+        for (void* p : blocks) (void)hipFree(p);
+    }
+};
+
+static TensorDesc make_desc(int n, int h, int w, int c, int ring, int ring_br) {
+    TensorDesc t;
+    t.ptr = nullptr;
+    t.n = n; t.h = h; t.w = w; t.c = c; t.ring = ring;
+    t.hp = h + ring + ring_br;
+    t.wp = w + ring + ring_br;
+    return t;
+}
+
+struct ConvOp {
+    TensorDesc in, out, res;
+    bool has_res = false;
+    half_t* w = nullptr;
+    float* bias = nullptr;
+    int* ktab = nullptr;
+    int K = 0, cout = 0, cout_pad = 0, stride = 1, in_y0 = 0, in_x0 = 0, flags = 0, ps_cout = 0, res_shift = 0;
+    int ho = 0, wo = 0;           // GEMM row decomposition (input-pixel grid for transposed conv)
+    int64_t macs_per_image = 0;
+    void* out_f32 = nullptr;      // EPI_OUT_F32 destination
+    int ldc = 0;
+};
+
+struct Op {
+    enum Kind { CONV, POOL, FINAL } kind;
+    ConvOp conv;
+    TensorDesc pin, pout;
+    int pk[6] = {0, 0, 0, 0, 0, 0};  // kh,kw,sh,sw,ph,pw
+    const float* fw = nullptr;
+    float fbias = 0.f;
+    int final_slot = 0;  // 0 = probability, 1 = threshold
+};
+
+static int launch_conv_op(const ConvOp& c, int n, hipStream_t s) {
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = c.in.ptr; p.wgt = c.w; p.ktab = c.ktab; p.bias = c.bias;
+    p.res = c.has_res ? c.res.ptr : nullptr;
+    p.out = (c.flags & EPI_OUT_F32) ? c.out_f32 : (void*)c.out.ptr;
+    p.M = n * c.ho * c.wo; p.K = c.K; p.cout = c.cout; p.cout_pad = c.cout_pad;
+    p.ho = c.ho; p.wo = c.wo;
+    p.in_hp = c.in.hp; p.in_wp = c.in.wp; p.in_c = c.in.c; p.in_y0 = c.in_y0; p.in_x0 = c.in_x0; p.stride = c.stride;
+    p.out_hp = c.out.hp; p.out_wp = c.out.wp; p.out_c = c.out.c; p.out_ring = c.out.ring;
+    p.res_hp = c.res.hp; p.res_wp = c.res.wp; p.res_ring = c.res.ring; p.res_shift = c.res_shift;
+    p.ps_cout = c.ps_cout; p.flags = c.flags; p.ldc = c.ldc;
+    return vtd_launch_conv(p, s);
+}
+
+// ---- Pillow resample coefficient tables (8-bit path, bilinear filter with antialias support scaling)
+struct ResampleAxis {
+    int ksize = 0;
+    std::vector<int> bounds, kk;
+};
+static ResampleAxis pillow_axis(int in_size, int out_size) {
+    ResampleAxis a;
+    const double scale = (double)in_size / out_size;
+    const double fscale = scale < 1.0 ? 1.0 : scale;
+    const double support = fscale;  // bilinear support 1.0 * filterscale
+    a.ksize = (int)std::ceil(support) * 2 + 1;
+    a.bounds.assign(2 * (size_t)out_size, 0);
+    a.kk.assign((size_t)out_size * a.ksize, 0);
+    std::vector<double> pre(a.ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale, ss = 1.0 / fscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            double t = (x + xmin - center + 0.5) * ss;
+            if (t < 0) t = -t;
+            const double wv = t < 1.0 ? 1.0 - t : 0.0;
+            pre[x] = wv;
+            ww += wv;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            const double v = ww != 0.0 ? pre[x] / ww : pre[x];
+            a.kk[(size_t)xx * a.ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+        }
+        a.bounds[2 * xx] = xmin;
+        a.bounds[2 * xx + 1] = xmax;
+    }
+    return a;
+}
+
+struct PreTables {
+    int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr;
+    int ksx = 0, ksy = 0, max_rows = 0;
+};
+
+}  // namespace vtd
+
+using namespace vtd;
+
+struct vtd_detector {
+    std::string backbone;
+    int max_batch = 0;
+    bool finalized = false;
+    StateDict sd;
+    DeviceArena arena;
+    std::vector<Op> ops;
+    TensorDesc input;
+    std::map<std::string, TensorDesc> taps;
+    std::map<std::pair<int, int>, PreTables> pre;
+    int64_t macs = 0;
+    float* final_out[2] = {nullptr, nullptr};
+
+    int alloc_tensor(TensorDesc& t) {
+        void* p = nullptr;
+        int rc = arena.alloc(&p, (size_t)tensor_elems(t) * sizeof(half_t), true);
+        t.ptr = (half_t*)p;
+        return rc;
+    }
+    const std::vector<float>* get(const std::string& k, size_t numel) const {
+        auto it = sd.find(k);
+        if (it == sd.end() || it->second.size() != numel) return nullptr;
+        return &it->second;
+    }
+};
+
+namespace vtd {
+
+struct Fold {
+    std::vector<double> scale, shift;  // y = conv*scale + shift
+};
+
+// BatchNorm (eval) folded with an optional conv bias: y = (conv + b - mean) * g/sqrt(var+eps) + beta
+static int fold_bn(const vtd_detector* d, const std::string& bn, const std::string& bias_key, int cout, Fold& f) {
+    f.scale.assign(cout, 1.0);
+    f.shift.assign(cout, 0.0);
+    const std::vector<float>* b = nullptr;
+    if (!bias_key.empty()) {
+        b = d->get(bias_key, cout);
+        if (!b) return ERR_MISSING_KEY;
+    }
+    if (!bn.empty()) {
+        auto g = d->get(bn + ".weight", cout), be = d->get(bn + ".bias", cout), mu = d->get(bn + ".running_mean", cout),
+             var = d->get(bn + ".running_var", cout);
+        if (!g || !be || !mu || !var) return ERR_MISSING_KEY;
+        for (int c = 0; c < cout; ++c) {
+            const double s = (double)(*g)[c] / std::sqrt((double)(*var)[c] + 1e-5);
+            f.scale[c] = s;
+            f.shift[c] = (double)(*be)[c] + ((b ? (double)(*b)[c] : 0.0) - (double)(*mu)[c]) * s;
+        }
+    } else if (b) {
+        for (int c = 0; c < cout; ++c) f.shift[c] = (*b)[c];
+    }
+    return 0;
+}
+
+static int upload(DeviceArena& arena, const void* host, size_t bytes, void** dev) {
+    int rc = arena.alloc(dev, bytes, false);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Generic conv: weights [cout, cin, kh, kw]; K order (r, s, c) over the input's channel stride.
+static int build_conv(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey,
+                      const Fold& f, int cin, int cout, int kh, int kw, int stride, int pad, int flags) {
+    auto w = d->get(wkey, (size_t)cout * cin * kh * kw);
+    if (!w) return ERR_MISSING_KEY;
+    if (in.c != cin || (cin & 63) || in.ring < pad) return ERR_GEOMETRY;
+    const int ho = (in.h + 2 * pad - kh) / stride + 1, wo = (in.w + 2 * pad - kw) / stride + 1;
+    if (out.h != ho || out.w != wo || out.c != cout) return ERR_GEOMETRY;
+    const int K = kh * kw * cin;
+    const int cout_pad = (cout + 63) / 64 * 64;
+    std::vector<half_t> wp((size_t)cout_pad * K, (half_t)0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int c = 0; c < cin; ++c)
+            for (int r = 0; r < kh; ++r)
+                for (int s = 0; s < kw; ++s)
+                    wp[(size_t)co * K + (size_t)(r * kw + s) * cin + c] =
+                        (half_t)(float)((double)(*w)[(((size_t)co * cin + c) * kh + r) * kw + s] * f.scale[co]);
+    std::vector<float> bias(cout_pad, 0.f);
+    for (int co = 0; co < cout; ++co) bias[co] = (float)f.shift[co];
+    std::vector<int> ktab(K / 8);
+    for (int q = 0; q < K / 8; ++q) {
+        const int k = q * 8, tap = k / cin, c0 = k % cin, r = tap / kw, s = tap % kw;
+        ktab[q] = (r * in.wp + s) * in.c + c0;
+    }
+    int rc;
+    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
+    op.in = in; op.out = out; op.K = K; op.cout = cout; op.cout_pad = cout_pad; op.stride = stride;
+    op.in_y0 = in.ring - pad; op.in_x0 = in.ring - pad; op.flags = flags; op.ho = ho; op.wo = wo;
+    op.macs_per_image = (int64_t)ho * wo * cout * K;
+    // last tap of the last output pixel must be inside the padded input
+    if ((ho - 1) * stride + op.in_y0 + kh - 1 >= in.hp || (wo - 1) * stride + op.in_x0 + kw - 1 >= in.wp) return ERR_GEOMETRY;
+    return 0;
+}
+
+// Stem: conv 7x7/s2/p3 on the ring-3 NHWC4 input.  K is laid out as 8 kernel rows x (8 taps x 4 ch):
+// one kernel row = 64 contiguous bytes of the input, rows 7 / taps 7 / channel 3 carry zero weights.
+static int build_stem(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f) {
+    auto w = d->get(wkey, (size_t)64 * 3 * 7 * 7);
+    if (!w) return ERR_MISSING_KEY;
+    if (in.c != 4 || in.ring != 3 || in.hp != in.h + 6 || in.wp != in.w + 6 || out.h != in.h / 2 || out.w != in.w / 2 || out.c != 64)
+        return ERR_GEOMETRY;
+    const int K = 256;
+    std::vector<half_t> wp((size_t)64 * K, (half_t)0.f);
+    for (int co = 0; co < 64; ++co)
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 7; ++r)
+                for (int s = 0; s < 7; ++s)
+                    wp[(size_t)co * K + r * 32 + s * 4 + c] = (half_t)(float)((double)(*w)[(((size_t)co * 3 + c) * 7 + r) * 7 + s] * f.scale[co]);
+    std::vector<float> bias(64);
+    for (int co = 0; co < 64; ++co) bias[co] = (float)f.shift[co];
+    std::vector<int> ktab(K / 8);
+    for (int q = 0; q < K / 8; ++q) {
+        const int k = q * 8, r = k / 32, within = k % 32;
+        ktab[q] = r * in.wp * 4 + within;
+    }
+    int rc;
+    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
+    op.in = in; op.out = out; op.K = K; op.cout = 64; op.cout_pad = 64; op.stride = 2;
+    op.in_y0 = 0; op.in_x0 = 0; op.flags = EPI_RELU; op.ho = out.h; op.wo = out.w;
+    op.macs_per_image = (int64_t)out.h * out.w * 64 * 147;
+    if ((out.h - 1) * 2 + 7 >= in.hp || (out.w - 1) * 2 + 7 >= in.wp) return ERR_GEOMETRY;
+    return 0;
+}
+
+// ConvTranspose2d(cin -> cout, k=2, s=2), weights [cin, cout, 2, 2]: GEMM with N = 4*cout and a pixel-shuffle store.
+static int build_convt(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f,
+                       int cin, int cout, int flags) {
+    auto w = d->get(wkey, (size_t)cin * cout * 4);
+    if (!w) return ERR_MISSING_KEY;
+    if (in.c != cin || (cin & 63) || out.h != 2 * in.h || out.w != 2 * in.w || out.c != cout || (cout & 15)) return ERR_GEOMETRY;
+    const int K = cin, N = 4 * cout, cout_pad = (N + 63) / 64 * 64;
+    std::vector<half_t> wp((size_t)cout_pad * K, (half_t)0.f);
+    std::vector<float> bias(cout_pad, 0.f);
+    for (int blk = 0; blk < 4; ++blk)
+        for (int co = 0; co < cout; ++co) {
+            const int nrow = blk * cout + co;
+            bias[nrow] = (float)f.shift[co];
+            for (int ci = 0; ci < cin; ++ci)
+                wp[(size_t)nrow * K + ci] = (half_t)(float)((double)(*w)[((size_t)ci * cout + co) * 4 + blk] * f.scale[co]);
+        }
+    std::vector<int> ktab(K / 8);
+    for (int q = 0; q < K / 8; ++q) ktab[q] = q * 8;
+    int rc;
+    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
+    op.in = in; op.out = out; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
+    op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = flags | EPI_PIXEL_SHUFFLE; op.ps_cout = cout;
+    op.ho = in.h; op.wo = in.w;
+    op.macs_per_image = (int64_t)in.h * in.w * N * K;
+    return 0;
+}
+
+static const int kStageWidth[4] = {64, 128, 256, 512};
+
+static int build_detector_graph(vtd_detector* d) {
+    const bool r50 = d->backbone == "resnet50";
+    const int counts18[4] = {2, 2, 2, 2}, counts50[4] = {3, 4, 6, 3};
+    const int* counts = r50 ? counts50 : counts18;
+    const int B = d->max_batch;
+    int rc;
+    auto new_tensor = [&](int h, int w, int c, TensorDesc& t) {
+        t = make_desc(B, h, w, c, 1, 1);
+        return d->alloc_tensor(t);
+    };
+    auto push_conv = [&](const ConvOp& c) {
+        Op o;
+        o.kind = Op::CONV;
+        o.conv = c;
+        d->ops.push_back(o);
+        d->macs += c.macs_per_image;
+    };
+
+    d->input = make_desc(B, 640, 640, 4, 3, 3);
+    if ((rc = d->alloc_tensor(d->input))) return rc;
+    d->taps["input"] = d->input;
+
+    // stem + maxpool
+    TensorDesc stem, x;
+    if ((rc = new_tensor(320, 320, 64, stem))) return rc;
+    {
+        Fold f;
+        if ((rc = fold_bn(d, "backbone.1", "", 64, f))) return rc;
+        ConvOp c;
+        if ((rc = build_stem(d, c, d->input, stem, "backbone.0.weight", f))) return rc;
+        push_conv(c);
+    }
+    d->taps["stem"] = stem;
+    if ((rc = new_tensor(160, 160, 64, x))) return rc;
+    {
+        Op o;
+        o.kind = Op::POOL;
+        o.pin = stem; o.pout = x;
+        const int pk[6] = {3, 3, 2, 2, 1, 1};
+        std::memcpy(o.pk, pk, sizeof(pk));
+        d->ops.push_back(o);
+    }
+
+    // residual stages
+    TensorDesc tapsC[4];
+    int cin = 64;
+    for (int st = 0; st < 4; ++st) {
+        const int width = kStageWidth[st];
+        const int cout = r50 ? width * 4 : width;
+        for (int b = 0; b < counts[st]; ++b) {
+            const int stride = (b == 0 && st > 0) ? 2 : 1;
+            const std::string pre = "backbone." + std::to_string(4 + st) + "." + std::to_string(b);
+            const int hin = x.h, hout = hin / stride;
+            TensorDesc idt = x;
+            if (stride != 1 || cin != cout) {
+                TensorDesc ds;
+                if ((rc = new_tensor(hout, hout, cout, ds))) return rc;
+                Fold f;
+                if ((rc = fold_bn(d, pre + ".downsample.1", "", cout, f))) return rc;
+                ConvOp c;
+                if ((rc = build_conv(d, c, x, ds, pre + ".downsample.0.weight", f, cin, cout, 1, 1, stride, 0, 0))) return rc;
+                push_conv(c);
+                idt = ds;
+            }
+            TensorDesc y;
+            if (!r50) {
+                TensorDesc t1;
+                if ((rc = new_tensor(hout, hout, width, t1))) return rc;
+                Fold f1, f2;
+                if ((rc = fold_bn(d, pre + ".bn1", "", width, f1))) return rc;
+                ConvOp c1;
+                if ((rc = build_conv(d, c1, x, t1, pre + ".conv1.weight", f1, cin, width, 3, 3, stride, 1, EPI_RELU))) return rc;
+                push_conv(c1);
+                if ((rc = new_tensor(hout, hout, width, y))) return rc;
+                if ((rc = fold_bn(d, pre + ".bn2", "", width, f2))) return rc;
+                ConvOp c2;
+                if ((rc = build_conv(d, c2, t1, y, pre + ".conv2.weight", f2, width, width, 3, 3, 1, 1, EPI_RELU | EPI_RESIDUAL))) return rc;
+                c2.has_res = true; c2.res = idt; c2.res_shift = 0;
+                push_conv(c2);
+            } else {
+                TensorDesc t1, t2;
+                if ((rc = new_tensor(hin, hin, width, t1))) return rc;
+                Fold f1, f2, f3;
+                if ((rc = fold_bn(d, pre + ".bn1", "", width, f1))) return rc;
+                ConvOp c1;
+                if ((rc = build_conv(d, c1, x, t1, pre + ".conv1.weight", f1, cin, width, 1, 1, 1, 0, EPI_RELU))) return rc;
+                push_conv(c1);
+                if ((rc = new_tensor(hout, hout, width, t2))) return rc;
+                if ((rc = fold_bn(d, pre + ".bn2", "", width, f2))) return rc;
+                ConvOp c2;
+                if ((rc = build_conv(d, c2, t1, t2, pre + ".conv2.weight", f2, width, width, 3, 3, stride, 1, EPI_RELU))) return rc;
+                push_conv(c2);
+                if ((rc = new_tensor(hout, hout, cout, y))) return rc;
+                if ((rc = fold_bn(d, pre + ".bn3", "", cout, f3))) return rc;
+                ConvOp c3;
+                if ((rc = build_conv(d, c3, t2, y, pre + ".conv3.weight", f3, width, cout, 1, 1, 1, 0, EPI_RELU | EPI_RESIDUAL))) return rc;
+                c3.has_res = true; c3.res = idt; c3.res_shift = 0;
+                push_conv(c3);
+            }
+            x = y;
+            cin = cout;
+        }
+        tapsC[st] = x;
+        d->taps["c" + std::to_string(st + 2)] = x;
+    }
+
+    // FPN, intended wiring: inner[i] on C5,C4,C3,C2; top-down nearest-2x add fused in the epilogue
+    TensorDesc last;
+    for (int i = 0; i < 4; ++i) {
+        const TensorDesc& feat = tapsC[3 - i];
+        TensorDesc lat;
+        if ((rc = new_tensor(feat.h, feat.w, 256, lat))) return rc;
+        Fold f;
+        const std::string k = "fpn.inner_blocks." + std::to_string(i);
+        if ((rc = fold_bn(d, "", k + ".bias", 256, f))) return rc;
+        ConvOp c;
+        if ((rc = build_conv(d, c, feat, lat, k + ".weight", f, feat.c, 256, 1, 1, 1, 0, i ? EPI_RESIDUAL : 0))) return rc;
+        if (i) { c.has_res = true; c.res = last; c.res_shift = 1; }
+        push_conv(c);
+        last = lat;
+    }
+    TensorDesc p2;
+    if ((rc = new_tensor(160, 160, 256, p2))) return rc;
+    {
+        Fold f;
+        if ((rc = fold_bn(d, "", "fpn.layer_blocks.3.bias", 256, f))) return rc;
+        ConvOp c;
+        if ((rc = build_conv(d, c, last, p2, "fpn.layer_blocks.3.weight", f, 256, 256, 3, 3, 1, 1, 0))) return rc;
+        push_conv(c);
+    }
+    d->taps["p2"] = p2;
+    // layer_blocks.0..2 exist in checkpoints but their outputs are dead (text_detector.py:56); still validated
+    for (int i = 0; i < 3; ++i) {
+        const std::string k = "fpn.layer_blocks." + std::to_string(i);
+        if (!d->get(k + ".weight", (size_t)256 * 256 * 9) || !d->get(k + ".bias", 256)) return ERR_MISSING_KEY;
+    }
+
+    // DB head branches (probability always; threshold provisioned, run on demand)
+    const char* branch[2] = {"head.probability_head.", "head.threshold_head."};
+    for (int br = 0; br < 2; ++br) {
+        const std::string hp = branch[br];
+        TensorDesc h1, h2;
+        if ((rc = new_tensor(160, 160, 64, h1))) return rc;
+        if ((rc = new_tensor(320, 320, 64, h2))) return rc;
+        Fold f1, f2;
+        if ((rc = fold_bn(d, hp + "1", hp + "0.bias", 64, f1))) return rc;
+        ConvOp c1;
+        if ((rc = build_conv(d, c1, p2, h1, hp + "0.weight", f1, 256, 64, 3, 3, 1, 1, EPI_RELU))) return rc;
+        if ((rc = fold_bn(d, hp + "4", hp + "3.bias", 64, f2))) return rc;
+        ConvOp c2;
+        if ((rc = build_convt(d, c2, h1, h2, hp + "3.weight", f2, 64, 64, EPI_RELU))) return rc;
+        auto w6 = d->get(hp + "6.weight", 64 * 4), b6 = d->get(hp + "6.bias", 1);
+        if (!w6 || !b6) return ERR_MISSING_KEY;
+        std::vector<float> wf(4 * 64);
+        for (int blk = 0; blk < 4; ++blk)
+            for (int ci = 0; ci < 64; ++ci) wf[blk * 64 + ci] = (*w6)[ci * 4 + blk];
+        float* wdev = nullptr;
+        if ((rc = upload(d->arena, wf.data(), wf.size() * sizeof(float), (void**)&wdev))) return rc;
+        Op o1, o2, o3;
+        o1.kind = Op::CONV; o1.conv = c1; o1.final_slot = br;
+        o2.kind = Op::CONV; o2.conv = c2; o2.final_slot = br;
+        o3.kind = Op::FINAL; o3.pin = h2; o3.fw = wdev; o3.fbias = (*b6)[0]; o3.final_slot = br;
+        d->ops.push_back(o1);
+        d->ops.push_back(o2);
+        d->ops.push_back(o3);
+        if (br == 0) {
+            d->macs += c1.macs_per_image + c2.macs_per_image + (int64_t)320 * 320 * 4 * 64;
+            d->taps["head1"] = h1;
+            d->taps["head2"] = h2;
+        }
+    }
+    return 0;
+}
+
+static bool known_detector_key(const std::string& k) {
+    return k.rfind("backbone.", 0) == 0 || k.rfind("fpn.", 0) == 0 || k.rfind("head.", 0) == 0;
+}
+
+static int get_pre_tables(vtd_detector* d, int H, int W, PreTables& out) {
+    auto key = std::make_pair(H, W);
+    auto it = d->pre.find(key);
+    if (it != d->pre.end()) {
+        out = it->second;
+        return 0;
+    }
+    ResampleAxis ax = pillow_axis(W, 640), ay = pillow_axis(H, 640);
+    PreTables t;
+    t.ksx = ax.ksize; t.ksy = ay.ksize;
+    int max_rows = 0;
+    for (int oy0 = 0; oy0 < 640; oy0 += 16) {
+        const int last = std::min(oy0 + 16, 640) - 1;
+        max_rows = std::max(max_rows, ay.bounds[2 * last] + ay.bounds[2 * last + 1] - ay.bounds[2 * oy0]);
+    }
+    t.max_rows = max_rows;
+    int rc;
+    if ((rc = upload(d->arena, ax.bounds.data(), ax.bounds.size() * sizeof(int), (void**)&t.xb))) return rc;
+    if ((rc = upload(d->arena, ax.kk.data(), ax.kk.size() * sizeof(int), (void**)&t.xk))) return rc;
+    if ((rc = upload(d->arena, ay.bounds.data(), ay.bounds.size() * sizeof(int), (void**)&t.yb))) return rc;
+    if ((rc = upload(d->arena, ay.kk.data(), ay.kk.size() * sizeof(int), (void**)&t.yk))) return rc;
+    d->pre[key] = t;
+    out = t;
+    return 0;
+}
+
+}  // namespace vtd
+
+extern "C" {
+
+const char* vtd_version(void) { return "vtd_hip 0.1 (gfx950)"; }
+
+const char* vtd_strerror(int code) {
+    static thread_local char buf[128];
+    switch (code) {
+        case 0: return "ok";
+        case ERR_ARG: return "invalid argument";
+        case ERR_UNKNOWN_KEY: return "unknown state-dict key";
+        case ERR_SHAPE: return "tensor has the wrong number of elements";
+        case ERR_MISSING_KEY: return "state dict incomplete (missing or mis-sized key)";
+        case ERR_NOT_FINALIZED: return "handle not finalized";
+        case ERR_BATCH: return "batch exceeds the handle's max_batch";
+        case ERR_GEOMETRY: return "layer geometry check failed";
+        case ERR_CAPACITY: return "output capacity too small";
+        default: break;
+    }
+    if (code <= -1000) {
+        std::snprintf(buf, sizeof(buf), "vtd validation error %d", code);
+        return buf;
+    }
+    if (code < 0) return hipGetErrorString((hipError_t)(-code));
+    return "unknown";
+}
+
+int vtd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    return e == hipSuccess ? n : -(int)e;
+}
+
+int vtd_detector_create(const char* backbone, int max_batch, vtd_detector** out) {
+    if (!backbone || !out || max_batch <= 0) return ERR_ARG;
+    const std::string b = backbone;
+    if (b != "resnet18" && b != "resnet50") return ERR_ARG;
+    auto* d = new vtd_detector();
+    d->backbone = b;
+    d->max_batch = max_batch;
+    *out = d;
+    return 0;
+}
+
+void vtd_detector_destroy(vtd_detector* d) { delete d; }
+
+int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_data, int64_t numel) {
+    if (!d || !key || !host_data || numel < 0) return ERR_ARG;
+    const std::string k = key;
+    if (!known_detector_key(k)) return ERR_UNKNOWN_KEY;
+    if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return 0;
+    d->sd[k].assign(host_data, host_data + numel);
+    return 0;
+}
+
+int vtd_detector_finalize(vtd_detector* d, vtd_stream stream) {
+    if (!d) return ERR_ARG;
+    if (d->finalized) return ERR_ARG;
+    int rc = build_detector_graph(d);
+    if (rc) return rc;
+    void* p = nullptr;
+    for (int i = 0; i < 2; ++i) d->final_out[i] = nullptr;
+    (void)p;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return -(int)e;
+    d->sd.clear();
+    d->finalized = true;
+    return 0;
+}
+
+int vtd_detector_preprocess(vtd_detector* d, const uint8_t* frames_dev, int n, int height, int width, vtd_stream stream) {
+    if (!d || !frames_dev || height <= 0 || width <= 0) return ERR_ARG;
+    if (!d->finalized) return ERR_NOT_FINALIZED;
+    if (n <= 0 || n > d->max_batch) return ERR_BATCH;
+    PreTables t;
+    int rc = get_pre_tables(d, height, width, t);
+    if (rc) return rc;
+    return vtd_launch_preprocess(frames_dev, n, height, width, d->input.ptr, t.xb, t.xk, t.ksx, t.yb, t.yk, t.ksy, t.max_rows,
+                                 (hipStream_t)stream);
+}
+
+int vtd_detector_set_input_nchw(vtd_detector* d, const float* x_dev, int n, vtd_stream stream) {
+    if (!d || !x_dev) return ERR_ARG;
+    if (!d->finalized) return ERR_NOT_FINALIZED;
+    if (n <= 0 || n > d->max_batch) return ERR_BATCH;
+    return vtd_launch_nchw_to_input(x_dev, d->input.ptr, n, (hipStream_t)stream);
+}
+
+int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_dev, vtd_stream stream) {
+    if (!d || !prob_dev) return ERR_ARG;
+    if (!d->finalized) return ERR_NOT_FINALIZED;
+    if (n <= 0 || n > d->max_batch) return ERR_BATCH;
+    hipStream_t s = (hipStream_t)stream;
+    float* outs[2] = {prob_dev, thresh_dev};
+    for (const Op& o : d->ops) {
+        int rc = 0;
+        if (o.final_slot == 1 && !thresh_dev) continue;
+        switch (o.kind) {
+            case Op::CONV: rc = launch_conv_op(o.conv, n, s); break;
+            case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
+            case Op::FINAL: rc = vtd_launch_final_convt_sigmoid(o.pin, o.fw, o.fbias, outs[o.final_slot], n, s); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_out, int64_t capacity, vtd_stream stream) {
+    if (!d || !name || !host_out) return ERR_ARG;
+    if (!d->finalized) return ERR_NOT_FINALIZED;
+    auto it = d->taps.find(name);
+    if (it == d->taps.end()) return ERR_UNKNOWN_KEY;
+    const TensorDesc& t = it->second;
+    if (n <= 0 || n > t.n) return ERR_BATCH;
+    const int creal = (std::string(name) == "input") ? 3 : t.c;
+    if (capacity < (int64_t)n * creal * t.h * t.w) return ERR_CAPACITY;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return -(int)e;
+    std::vector<half_t> tmp((size_t)n * t.hp * t.wp * t.c);
+    e = hipMemcpy(tmp.data(), t.ptr, tmp.size() * sizeof(half_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int)e;
+    for (int img = 0; img < n; ++img)
+        for (int c = 0; c < creal; ++c)
+            for (int y = 0; y < t.h; ++y)
+                for (int x = 0; x < t.w; ++x)
+                    host_out[(((size_t)img * creal + c) * t.h + y) * t.w + x] =
+                        (float)tmp[(((size_t)img * t.hp + y + t.ring) * t.wp + x + t.ring) * t.c + c];
+    return 0;
+}
+
+int64_t vtd_detector_macs_per_frame(const vtd_detector* d) { return d ? d->macs : 0; }
+
+}  // extern "C"

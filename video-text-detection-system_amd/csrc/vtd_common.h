@@ -1,0 +1,63 @@
+// Internal shared definitions for the gfx950 HIP kernels (not part of the C ABI; see include/vtd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef half_t half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define VTD_AS1 __attribute__((address_space(1)))
+#define VTD_AS3 __attribute__((address_space(3)))
+
+// Activation tensor in HBM: NHWC fp16 with a zero ring of `ring` pixels on every side of every image
+// (ring_b/ring_r may be larger on the network input).  Rings are zeroed once at allocation and never
+// written, so 3x3/7x7 taps need no bounds checks and `buffer/global_load ... lds` can fetch them blind.
+struct TensorDesc {
+    half_t* ptr;
+    int n, h, w, c;   // logical extents
+    int ring;         // top/left ring (pixels)
+    int hp, wp;       // padded extents (h + ring + ring_bottom, w + ring + ring_right)
+};
+
+static inline __host__ __device__ int64_t tensor_elems(const TensorDesc& t) {
+    return (int64_t)t.n * t.hp * t.wp * t.c;
+}
+
+// Epilogue modes of the implicit-GEMM convolution
+enum : int {
+    EPI_RELU = 1,          // max(x, 0)
+    EPI_RESIDUAL = 2,      // += res[n, oy>>res_shift, ox>>res_shift, ch]   (res_shift=1: fused nearest-2x upsample)
+    EPI_PIXEL_SHUFFLE = 4, // ConvTranspose2d(k=2,s=2) as GEMM: channel block q=(ky*2+kx) -> pixel (2oy+ky, 2ox+kx)
+    EPI_OUT_F32 = 8,       // plain [M, ldc] float32 row-major output (LSTM gate pre-activations, logits)
+};
+
+struct ConvParams {
+    const half_t* in;      // input tensor base (ring-padded NHWC)
+    const half_t* wgt;     // packed weights [Cout_pad][K] fp16, K contiguous, K order given by ktab
+    const int* ktab;       // per 16-byte K-chunk: element offset from the tap-(0,0) pixel of the output position
+    const float* bias;     // [Cout_pad] fp32 (conv bias and BatchNorm folded)
+    const half_t* res;     // optional residual tensor (ring-padded NHWC, C = cout)
+    void* out;             // output tensor base
+    int M;                 // n * ho * wo
+    int K;                 // multiple of 64
+    int cout;              // valid output channels
+    int cout_pad;          // multiple of BN
+    int ho, wo;            // output spatial extents (GEMM rows decompose to n, oy, ox)
+    int in_hp, in_wp, in_c; // padded input extents and channel stride (elements per pixel)
+    int in_y0, in_x0;      // ring_in - pad
+    int stride;
+    int out_hp, out_wp, out_c, out_ring;
+    int res_hp, res_wp, res_ring, res_shift;
+    int ps_cout;           // pixel-shuffle: channels per (ky,kx) block
+    int flags;
+    int ldc;               // EPI_OUT_F32 row stride
+};
+
+#define VTD_HIP_CHECK(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return -(int)_e;                \
+    } while (0)

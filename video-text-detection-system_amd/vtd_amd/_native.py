@@ -1,0 +1,69 @@
+"""ctypes binding of libvtd_hip.so (the C ABI in include/vtd.h).
+
+Loading is strict: there is no CPU or eager-PyTorch fallback anywhere in this package.  ``require()``
+raises when the library is missing (run ``python __graft_entry__.py`` / ``build_native.py``) or when
+no HIP device is visible, so a mis-provisioned GPU box fails loudly instead of silently passing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libvtd_hip.so")
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Detection(C.Structure):
+    _fields_ = [("bbox", C.c_int32 * 4), ("polygon", C.c_int32 * 8), ("confidence", C.c_float), ("area", C.c_float),
+                ("first_x", C.c_int32), ("first_y", C.c_int32)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/vtd.h
+SIGNATURES = {
+    "vtd_version": (C.c_char_p, []),
+    "vtd_strerror": (C.c_char_p, [C.c_int]),
+    "vtd_device_count": (C.c_int, []),
+    "vtd_detector_create": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vtd_detector_destroy": (None, [C.c_void_p]),
+    "vtd_detector_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "vtd_detector_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtd_detector_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtd_detector_set_input_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_detector_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vtd_detector_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vtd_detector_macs_per_frame": (C.c_int64, [C.c_void_p]),
+}
+
+
+def load():
+    """dlopen the library and bind every declared symbol (no device needed)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require():
+    """The library plus a visible GPU, or an exception.  Product code paths call this, never load()."""
+    lib = load()
+    n = lib.vtd_device_count()
+    if n <= 0:
+        raise NativeError("libvtd_hip.so loaded but no HIP device is visible; this package has no CPU fallback")
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().vtd_strerror(code)
+        raise NativeError(f"{what or 'vtd call'} failed: {msg.decode() if msg else code} ({code})")

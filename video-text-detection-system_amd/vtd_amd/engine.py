@@ -1,0 +1,123 @@
+"""Device engines: thin owners of the native handles (include/vtd.h) plus the torch tensors that
+serve as their caller-owned device buffers.  torch is plumbing here (allocation, streams); every
+FLOP is issued by libvtd_hip.so.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import _native
+
+DEFAULT_MAX_BATCH = int(os.environ.get("VTD_MAX_BATCH", "32"))
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceFrames:
+    """A batch of equally sized uint8 BGR HWC frames resident in HBM ([n,H,W,3] cuda tensor)."""
+
+    def __init__(self, frames):
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        elif isinstance(frames, (list, tuple)):
+            frames = torch.from_numpy(np.ascontiguousarray(np.stack(frames)))
+        if frames.dim() == 3:
+            frames = frames.unsqueeze(0)
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("frames must be uint8 [n,H,W,3] (BGR)")
+        self.tensor = frames.to("cuda", non_blocking=True).contiguous()
+
+    @property
+    def n(self):
+        return self.tensor.shape[0]
+
+    @property
+    def height(self):
+        return self.tensor.shape[1]
+
+    @property
+    def width(self):
+        return self.tensor.shape[2]
+
+
+class DetectorEngine:
+    """DBNet on the GPU: reference checkpoint tensors in, [n,1,640,640] probability maps out."""
+
+    def __init__(self, backbone, state_dict, max_batch=None):
+        self.lib = _native.require()
+        self.max_batch = max_batch or DEFAULT_MAX_BATCH
+        self.backbone = backbone
+        self.lock = threading.Lock()  # a handle is single-stream; detect() may be entered from 4 threads
+        h = C.c_void_p()
+        _native.check(self.lib.vtd_detector_create(backbone.encode(), self.max_batch, C.byref(h)), "vtd_detector_create")
+        self.handle = h
+        try:
+            for key, value in state_dict.items():
+                if key.endswith("num_batches_tracked"):
+                    continue
+                arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
+                _native.check(self.lib.vtd_detector_set_tensor(h, key.encode(), arr.ctypes.data, arr.size),
+                              f"vtd_detector_set_tensor({key})")
+            _native.check(self.lib.vtd_detector_finalize(h, _stream_ptr()), "vtd_detector_finalize")
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vtd_detector_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def macs_per_frame(self):
+        return int(self.lib.vtd_detector_macs_per_frame(self.handle))
+
+    def _set_input(self, x):
+        if isinstance(x, DeviceFrames):
+            n = x.n
+            _native.check(self.lib.vtd_detector_preprocess(self.handle, C.c_void_p(x.tensor.data_ptr()), n, x.height, x.width,
+                                                           _stream_ptr()), "vtd_detector_preprocess")
+            return n, x
+        if not torch.is_tensor(x) or x.dim() != 4 or tuple(x.shape[1:]) != (3, 640, 640):
+            raise ValueError("DBNet input must be [n,3,640,640] float or a DeviceFrames batch")
+        xd = x.to("cuda", torch.float32).contiguous()
+        _native.check(self.lib.vtd_detector_set_input_nchw(self.handle, C.c_void_p(xd.data_ptr()), xd.shape[0], _stream_ptr()),
+                      "vtd_detector_set_input_nchw")
+        return xd.shape[0], xd
+
+    def forward(self, x, want_threshold=False):
+        with self.lock:
+            n, keep = self._set_input(x)
+            prob = torch.empty((n, 1, 640, 640), dtype=torch.float32, device="cuda")
+            thr = torch.empty_like(prob) if want_threshold else None
+            _native.check(self.lib.vtd_detector_forward(self.handle, n, C.c_void_p(prob.data_ptr()),
+                                                        C.c_void_p(thr.data_ptr()) if thr is not None else None, _stream_ptr()),
+                          "vtd_detector_forward")
+            del keep
+            return {"probability": prob, "threshold": thr}
+
+    def read_tap(self, name, n):
+        shapes = {"input": (3, 640, 640), "stem": (64, 320, 320), "p2": (256, 160, 160), "head1": (64, 160, 160),
+                  "head2": (64, 320, 320)}
+        if name not in shapes:
+            wide = self.backbone == "resnet50"
+            idx = int(name[1]) - 2
+            ch = (64, 128, 256, 512)[idx] * (4 if wide else 1)
+            shapes[name] = (ch, 160 >> idx, 160 >> idx)
+        c, h, w = shapes[name]
+        out = np.empty((n, c, h, w), np.float32)
+        with self.lock:
+            _native.check(self.lib.vtd_detector_read_tap(self.handle, name.encode(), n, out.ctypes.data, out.size, _stream_ptr()),
+                          f"vtd_detector_read_tap({name})")
+        return out
