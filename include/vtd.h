@@ -73,6 +73,17 @@ int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_
 /* Algorithmic live work of one frame through this detector, in MACs (for roofline accounting). */
 int64_t vtd_detector_macs_per_frame(const vtd_detector* d);
 
+/* ---- post-process: TextDetector._post_process (text_detector.py:143-178) ------------------------ */
+/* Workspace for maps of map_h x map_w (the reference hard-codes 640 in the bbox arithmetic but its tests feed
+ * 160x160 maps: any 2-D size works) and up to max_batch maps per call; max_out detections kept per frame. */
+int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_postproc** out);
+void vtd_postproc_destroy(vtd_postproc* pp);
+/* prob_dev: [n,map_h,map_w] float32.  orig_w/orig_h: frame sizes (host arrays of n).  Strict `p > threshold`.
+ * out_dev: [n,max_out] records in the order cv2.findContours(RETR_EXTERNAL) yields contours (reverse raster
+ * discovery); counts_dev[i] = number of detections of frame i before truncation to max_out. */
+int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
+                     float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

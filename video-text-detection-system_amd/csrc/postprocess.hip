@@ -1,0 +1,596 @@
+// Probability map -> detections on gfx950.  Replaces TextDetector._post_process
+// (app/ml/models/text_detector.py:143-178): strict threshold, cv2.findContours(RETR_EXTERNAL), contourArea >= 100,
+// minAreaRect -> boxPoints -> np.int0, bbox clamp/scale/size filter, mean-probability confidence.
+//
+// The reference walks contours one after another on the CPU.  Here every frame of the batch is
+// processed at once and nothing is traced:
+//   * external contours  = 8-connected components of the complement of the frame-connected background
+//                          (4-connected, image virtually zero padded): one lock-free union-find over all
+//                          pixels (atomicMin label equivalence) finds the frame background, a second pass
+//                          joins foreground, holes and nested islands into the filled components
+//   * contourArea        = lattice identity on the filled component: #2x2 blocks fully inside + 1/2 #blocks
+//                          with exactly three pixels inside (equals the shoelace area of the traced border)
+//   * minAreaRect        = per-row min/max x of the component -> two monotone chains -> strict hull ->
+//                          rotating calipers in float32, replayed in the published operation order
+//                          (this file is compiled with -ffp-contract=off)
+//   * ordering           = components are numbered by their raster-first pixel with block scans, the
+//                          surviving detections are emitted in reverse raster order (cv2 4.8.1's order)
+// All stages are HBM/L2-bound integer work; no host synchronisation happens between them.
+#include <float.h>
+#include <math.h>
+
+#include "../../include/vtd.h"
+#include "vtd_common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 1024;
+constexpr double VTD_PI = 3.1415926535897932384626433832795;
+
+struct PostWs {
+    const float* prob;  // [n, h, w]
+    int n, h, w, P;
+    float thr;
+    int* label;        // [n][P+1], index 0 = frame background sentinel, pixel i <-> i+1
+    uint8_t* flags;    // [n][P]  bit0 foreground, bit1 inside (not frame background)
+    int* compid;       // [n][P]  valid at component roots
+    int* ncomp;        // [n]
+    int maxc;          // capacity of the per-component arrays
+    int* area2;        // [n][maxc]  2 * contour area
+    int* bbox;         // [n][maxc][4] xmin,xmax,ymin,ymax
+    int* rowoff;       // [n][maxc]  -1 for non-candidates
+    int* candlist;     // [n][maxcand]
+    int* ncand;        // [n]
+    int maxcand;
+    int* rowmin;       // [n][P]
+    int* rowmax;       // [n][P]
+    int* hull;         // [n][P+8][12] scratch: chain stack, then hull points / calipers vect / inv_len
+    vtd_detection* cand_rec;  // [n][maxcand]
+    int* cand_valid;   // [n][maxcand]
+    const int* orig_w; // [n]
+    const int* orig_h; // [n]
+    vtd_detection* out; // [n][max_out]
+    int* out_count;    // [n]
+    int max_out;
+};
+
+__device__ __forceinline__ int ld_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int uf_find(const int* L, int a) {
+    int p = ld_relaxed(L + a);
+    while (p != a) {
+        a = p;
+        p = ld_relaxed(L + a);
+    }
+    return a;
+}
+
+// Lock-free union by minimum index: parents only ever decrease, so stale reads are harmless and the
+// atomicMin at the device-coherent point decides.
+__device__ __forceinline__ void uf_unite(int* L, int a, int b) {
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(L + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void pp_init(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        const int y = pix / ws.w, x = pix - y * ws.w;
+        const bool fg = ws.prob[i] > ws.thr;
+        const bool border = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1;
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        L[pix + 1] = (!fg && border) ? 0 : pix + 1;
+        if (pix == 0) L[0] = 0;
+        ws.flags[i] = fg ? 1 : 0;
+        ws.rowmin[i] = 0x7fffffff;
+        ws.rowmax[i] = -1;
+    }
+}
+
+__global__ void pp_merge_fg_bg(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        const int y = pix / ws.w, x = pix - y * ws.w;
+        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const int me = F[pix] & 1;
+        if (x > 0 && (F[pix - 1] & 1) == me) uf_unite(L, pix + 1, pix);
+        if (y > 0 && (F[pix - ws.w] & 1) == me) uf_unite(L, pix + 1, pix - ws.w + 1);
+        if (me && y > 0) {  // foreground is 8-connected: add the two diagonals
+            if (x > 0 && (F[pix - ws.w - 1] & 1)) uf_unite(L, pix + 1, pix - ws.w);
+            if (x < ws.w - 1 && (F[pix - ws.w + 1] & 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
+        }
+    }
+}
+
+__global__ void pp_classify(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const uint8_t fl = ws.flags[i];
+        bool inside = fl & 1;
+        if (!inside) inside = uf_find(L, pix + 1) != 0;  // background not connected to the frame = hole
+        ws.flags[i] = (uint8_t)((fl & 1) | (inside ? 2 : 0));
+    }
+}
+
+__global__ void pp_merge_inside(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+        if (!(F[pix] & 2)) continue;
+        const int y = pix / ws.w, x = pix - y * ws.w;
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        if (x > 0 && (F[pix - 1] & 2)) uf_unite(L, pix + 1, pix);
+        if (y > 0) {
+            if (F[pix - ws.w] & 2) uf_unite(L, pix + 1, pix - ws.w + 1);
+            if (x > 0 && (F[pix - ws.w - 1] & 2)) uf_unite(L, pix + 1, pix - ws.w);
+            if (x < ws.w - 1 && (F[pix - ws.w + 1] & 2)) uf_unite(L, pix + 1, pix - ws.w + 2);
+        }
+    }
+}
+
+__global__ void pp_flatten(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        if (!(ws.flags[i] & 2)) continue;
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        L[pix + 1] = uf_find(L, pix + 1);
+    }
+}
+
+// exclusive scan of one int per thread across a 1024-thread block; returns the exclusive prefix, *total = sum
+__device__ int block_exclusive_scan(int v, int* sh /* [2*SCAN_THREADS] */, int* total) {
+    const int t = threadIdx.x;
+    int* a = sh;
+    int* b = sh + SCAN_THREADS;
+    a[t] = v;
+    __syncthreads();
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+        b[t] = a[t] + (t >= d ? a[t - d] : 0);
+        __syncthreads();
+        int* tmp = a; a = b; b = tmp;
+    }
+    const int incl = a[t];
+    *total = a[SCAN_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+// one block per frame: number the components by raster order of their root (= raster-first pixel)
+__global__ __launch_bounds__(SCAN_THREADS) void pp_number_components(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    const int f = blockIdx.x;
+    const int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+    int* cid = ws.compid + (int64_t)f * ws.P;
+    const int chunk = (ws.P + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = threadIdx.x * chunk, hi = min(lo + chunk, ws.P);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += ((F[p] & 2) && L[p + 1] == p + 1) ? 1 : 0;
+    int total;
+    int base = block_exclusive_scan(cnt, sh, &total);
+    for (int p = lo; p < hi; ++p)
+        if ((F[p] & 2) && L[p + 1] == p + 1) cid[p] = base++;
+    if (total > ws.maxc) total = ws.maxc;  // cannot happen: maxc bounds the number of 8-connected components
+    if (threadIdx.x == 0) ws.ncomp[f] = total;
+    for (int c = threadIdx.x; c < total; c += SCAN_THREADS) {
+        ws.area2[(int64_t)f * ws.maxc + c] = 0;
+        int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
+        bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+    }
+}
+
+__global__ void pp_stats(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        const int y = pix / ws.w, x = pix - y * ws.w;
+        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const int* cid = ws.compid + (int64_t)f * ws.P;
+        const bool in00 = F[pix] & 2;
+        if (in00) {
+            const bool edge = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1 || !(F[pix - 1] & 2) || !(F[pix + 1] & 2) ||
+                              !(F[pix - ws.w] & 2) || !(F[pix + ws.w] & 2);
+            if (edge) {
+                int* bb = ws.bbox + ((int64_t)f * ws.maxc + cid[L[pix + 1] - 1]) * 4;
+                atomicMin(bb + 0, x); atomicMax(bb + 1, x); atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+            }
+        }
+        if (x < ws.w - 1 && y < ws.h - 1) {
+            const bool in10 = F[pix + 1] & 2, in01 = F[pix + ws.w] & 2, in11 = F[pix + ws.w + 1] & 2;
+            const int cnt = (int)in00 + (int)in10 + (int)in01 + (int)in11;
+            if (cnt >= 3) {
+                const int any = in00 ? pix : pix + 1;  // with >= 3 of 4 set one of the top two is set
+                atomicAdd(ws.area2 + (int64_t)f * ws.maxc + cid[L[any + 1] - 1], cnt == 4 ? 2 : 1);
+            }
+        }
+    }
+}
+
+// one block per frame: candidates (contourArea >= 100) in raster order + their row-table offsets
+__global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    const int f = blockIdx.x;
+    const int nc = ws.ncomp[f];
+    const int* area2 = ws.area2 + (int64_t)f * ws.maxc;
+    const int* bbox = ws.bbox + (int64_t)f * ws.maxc * 4;
+    int* rowoff = ws.rowoff + (int64_t)f * ws.maxc;
+    const int chunk = (nc + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(threadIdx.x * chunk, nc), hi = min(lo + chunk, nc);
+    int cnt = 0, rows = 0;
+    for (int c = lo; c < hi; ++c)
+        if (area2[c] >= 200) { cnt++; rows += bbox[4 * c + 3] - bbox[4 * c + 2] + 1; }
+    int tot_c, tot_r;
+    int base_c = block_exclusive_scan(cnt, sh, &tot_c);
+    int base_r = block_exclusive_scan(rows, sh, &tot_r);
+    for (int c = lo; c < hi; ++c) {
+        if (area2[c] >= 200 && base_c < ws.maxcand) {
+            ws.candlist[(int64_t)f * ws.maxcand + base_c] = c;
+            rowoff[c] = base_r;
+            base_c++;
+            base_r += bbox[4 * c + 3] - bbox[4 * c + 2] + 1;
+        } else {
+            rowoff[c] = -1;
+        }
+    }
+    if (threadIdx.x == 0) ws.ncand[f] = min(tot_c, ws.maxcand);
+}
+
+__global__ void pp_row_extents(const PostWs ws) {
+    const int64_t total = (int64_t)ws.n * ws.P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
+        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+        if (!(F[pix] & 2)) continue;
+        const int y = pix / ws.w, x = pix - y * ws.w;
+        const bool left = x == 0 || !(F[pix - 1] & 2), right = x == ws.w - 1 || !(F[pix + 1] & 2);
+        if (!left && !right) continue;
+        const int c = ws.compid[(int64_t)f * ws.P + ws.label[(int64_t)f * (ws.P + 1) + pix + 1] - 1];
+        const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
+        if (off < 0) continue;
+        const int r = off + y - ws.bbox[((int64_t)f * ws.maxc + c) * 4 + 2];
+        if (left) atomicMin(ws.rowmin + (int64_t)f * ws.P + r, x);
+        if (right) atomicMax(ws.rowmax + (int64_t)f * ws.P + r, x);
+    }
+}
+
+struct fpt { float x, y; };
+
+// rotating calipers, minimum-area rectangle (float32, published operation order); out[6]
+__device__ void min_area_rect_dev(const fpt* points, int n, fpt* vect, float* inv_len, float* out) {
+    float minarea = FLT_MAX;
+    int seq[4];
+    int left = 0, bottom = 0, right = 0, top = 0;
+    float orientation = 0, base_a, base_b = 0;
+    float left_x, right_x, top_y, bottom_y;
+    fpt pt0 = points[0];
+    left_x = right_x = pt0.x;
+    top_y = bottom_y = pt0.y;
+    for (int i = 0; i < n; i++) {
+        if (pt0.x < left_x) { left_x = pt0.x; left = i; }
+        if (pt0.x > right_x) { right_x = pt0.x; right = i; }
+        if (pt0.y > top_y) { top_y = pt0.y; top = i; }
+        if (pt0.y < bottom_y) { bottom_y = pt0.y; bottom = i; }
+        const fpt pt = points[(i + 1 < n) ? i + 1 : 0];
+        const double dx = (double)pt.x - (double)pt0.x, dy = (double)pt.y - (double)pt0.y;
+        vect[i].x = (float)dx;
+        vect[i].y = (float)dy;
+        inv_len[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+        pt0 = pt;
+    }
+    {
+        double ax = vect[n - 1].x, ay = vect[n - 1].y;
+        for (int i = 0; i < n; i++) {
+            const double bx = vect[i].x, by = vect[i].y;
+            const double convexity = ax * by - ay * bx;
+            if (convexity != 0) { orientation = (convexity > 0) ? 1.f : -1.f; break; }
+            ax = bx; ay = by;
+        }
+    }
+    base_a = orientation;
+    seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+    int best_left = 0, best_bottom = 0;
+    float best_a = 0, best_b = 0, best_w = 0, best_h = 0;
+    for (int k = 0; k < n; k++) {
+        float dp[4];
+        dp[0] = +base_a * vect[seq[0]].x + base_b * vect[seq[0]].y;
+        dp[1] = -base_b * vect[seq[1]].x + base_a * vect[seq[1]].y;
+        dp[2] = -base_a * vect[seq[2]].x - base_b * vect[seq[2]].y;
+        dp[3] = +base_b * vect[seq[3]].x - base_a * vect[seq[3]].y;
+        float maxcos = dp[0] * inv_len[seq[0]];
+        int main_element = 0;
+        for (int i = 1; i < 4; i++) {
+            const float cosalpha = dp[i] * inv_len[seq[i]];
+            if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; }
+        }
+        {
+            const int pindex = seq[main_element];
+            const float lead_x = vect[pindex].x * inv_len[pindex];
+            const float lead_y = vect[pindex].y * inv_len[pindex];
+            switch (main_element) {
+                case 0: base_a = lead_x; base_b = lead_y; break;
+                case 1: base_a = lead_y; base_b = -lead_x; break;
+                case 2: base_a = -lead_x; base_b = -lead_y; break;
+                default: base_a = -lead_y; base_b = lead_x; break;
+            }
+        }
+        seq[main_element] += 1;
+        seq[main_element] = (seq[main_element] == n) ? 0 : seq[main_element];
+        {
+            float dx = points[seq[1]].x - points[seq[3]].x;
+            float dy = points[seq[1]].y - points[seq[3]].y;
+            const float width = dx * base_a + dy * base_b;
+            dx = points[seq[2]].x - points[seq[0]].x;
+            dy = points[seq[2]].y - points[seq[0]].y;
+            const float height = -dx * base_b + dy * base_a;
+            const float area = width * height;
+            if (area <= minarea) {
+                minarea = area;
+                best_left = seq[3]; best_a = base_a; best_w = width;
+                best_b = base_b; best_h = height; best_bottom = seq[0];
+            }
+        }
+    }
+    {
+        const float A1 = best_a, B1 = best_b, A2 = -best_b, B2 = best_a;
+        const float C1 = A1 * points[best_left].x + points[best_left].y * B1;
+        const float C2 = A2 * points[best_bottom].x + points[best_bottom].y * B2;
+        const float idet = 1.f / (A1 * B2 - A2 * B1);
+        const float px = (C1 * B2 - C2 * B1) * idet;
+        const float py = (A1 * C2 - A2 * C1) * idet;
+        out[0] = px; out[1] = py;
+        out[2] = A1 * best_w; out[3] = B1 * best_w;
+        out[4] = A2 * best_h; out[5] = B2 * best_h;
+    }
+}
+
+__device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int bx, int by) {
+    return (long long)(ax - ox) * (by - oy) - (long long)(ay - oy) * (bx - ox);
+}
+
+// one wave per candidate: lane 0 builds hull + calipers + box, all lanes average the probability slice
+__global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
+    const int f = blockIdx.y, k = blockIdx.x;
+    if (k >= ws.ncand[f]) return;
+    __shared__ int sh_i[8];
+    const int c = ws.candlist[(int64_t)f * ws.maxcand + k];
+    const int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
+    const int ytop = bb[2], H = bb[3] - bb[2] + 1;
+    const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
+    vtd_detection rec;
+    if (threadIdx.x == 0) {
+        const int* rmin = ws.rowmin + (int64_t)f * ws.P + off;
+        const int* rmax = ws.rowmax + (int64_t)f * ws.P + off;
+        // scratch: 12 words per table row of this candidate.  The chain stack holds <= 2H+1 points; the strict
+        // hull has n <= 2H vertices and is converted to float in place, followed by vect[n] and inv_len[n]: 5n <= 10H.
+        int* st = ws.hull + ((int64_t)f * (ws.P + 8) + off) * 12;
+        int m = 0;
+        auto push_chain = [&](int base, int px, int py) {
+            while (m - base >= 2 && cross3(st[2 * (m - 2)], st[2 * (m - 2) + 1], st[2 * (m - 1)], st[2 * (m - 1) + 1], px, py) <= 0) m--;
+            st[2 * m] = px; st[2 * m + 1] = py; m++;
+        };
+        // chain 1: raster-first pixel, then the right ends of the rows going down
+        push_chain(0, rmin[0], ytop);
+        for (int r = 0; r < H; ++r) {
+            if (r == 0 && rmax[0] == rmin[0]) continue;
+            push_chain(0, rmax[r], ytop + r);
+        }
+        // chain 2: from the raster-last pixel up the left ends
+        const int base2 = m - 1;
+        for (int r = H - 1; r >= 0; --r) {
+            if (r == H - 1 && rmin[r] == rmax[r]) continue;
+            push_chain(base2, rmin[r], ytop + r);
+        }
+        // st[0] and st[m-1] are both the raster-first pixel: hull = st[1..m-1], clockwise on screen, ending there
+        const int n = m - 1;
+        fpt* pts = (fpt*)st;
+        fpt* vect = pts + n;
+        float* inv_len = (float*)(vect + n);
+        for (int i = 0; i < n; ++i) {  // in place, reading one point ahead of the write position
+            const int px = st[2 * (i + 1)], py = st[2 * (i + 1) + 1];
+            pts[i].x = (float)px; pts[i].y = (float)py;
+        }
+        float cx = 0, cy = 0, bw = 0, bh = 0, angle = 0;
+        if (n > 2) {
+            float o[6];
+            min_area_rect_dev(pts, n, vect, inv_len, o);
+            cx = o[0] + (o[2] + o[4]) * 0.5f;
+            cy = o[1] + (o[3] + o[5]) * 0.5f;
+            bw = (float)sqrt((double)o[2] * o[2] + (double)o[3] * o[3]);
+            bh = (float)sqrt((double)o[4] * o[4] + (double)o[5] * o[5]);
+            angle = (float)atan2((double)o[3], (double)o[2]);
+        } else if (n == 2) {
+            cx = (pts[0].x + pts[1].x) * 0.5f;
+            cy = (pts[0].y + pts[1].y) * 0.5f;
+            const double dx = (double)pts[1].x - pts[0].x, dy = (double)pts[1].y - pts[0].y;
+            bw = (float)sqrt(dx * dx + dy * dy);
+            angle = (float)atan2(dy, dx);
+        } else if (n == 1) {
+            cx = pts[0].x; cy = pts[0].y;
+        }
+        angle = (float)((double)(angle * 180.f) / VTD_PI);
+        const double rad = (double)angle * VTD_PI / 180.;
+        const float b = (float)cos(rad) * 0.5f;
+        const float a = (float)sin(rad) * 0.5f;
+        float p[8];
+        p[0] = cx - a * bh - b * bw;
+        p[1] = cy + b * bh - a * bw;
+        p[2] = cx + a * bh - b * bw;
+        p[3] = cy - b * bh - a * bw;
+        p[4] = 2 * cx - p[0];
+        p[5] = 2 * cy - p[1];
+        p[6] = 2 * cx - p[2];
+        p[7] = 2 * cy - p[3];
+        int xmin = 0x7fffffff, xmax = -0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
+        for (int i = 0; i < 4; ++i) {
+            const int xi = (int)p[2 * i], yi = (int)p[2 * i + 1];  // np.int0: truncate toward zero
+            rec.polygon[2 * i] = xi; rec.polygon[2 * i + 1] = yi;
+            xmin = min(xmin, xi); xmax = max(xmax, xi); ymin = min(ymin, yi); ymax = max(ymax, yi);
+        }
+        const long long ow = ws.orig_w[f], oh = ws.orig_h[f];
+        // text_detector.py:160-166 -- clamp to the literal 640, int(v * W / 640) (exact as integer division for v >= 0)
+        const long long x1 = (long long)max(0, xmin) * ow / 640, y1 = (long long)max(0, ymin) * oh / 640;
+        const long long x2 = (long long)min(640, xmax) * ow / 640, y2 = (long long)min(640, ymax) * oh / 640;
+        rec.bbox[0] = (int)x1; rec.bbox[1] = (int)y1; rec.bbox[2] = (int)x2; rec.bbox[3] = (int)y2;
+        const int valid = (x2 - x1 > 10 && y2 - y1 > 10) ? 1 : 0;
+        // text_detector.py:169-170 slice bounds with numpy clamping
+        sh_i[0] = valid;
+        sh_i[1] = (int)min((long long)ws.h, y1 * 640 / oh);
+        sh_i[2] = (int)min((long long)ws.h, y2 * 640 / oh);
+        sh_i[3] = (int)min((long long)ws.w, x1 * 640 / ow);
+        sh_i[4] = (int)min((long long)ws.w, x2 * 640 / ow);
+        rec.area = 0.5f * (float)ws.area2[(int64_t)f * ws.maxc + c];
+        rec.first_x = rmin[0]; rec.first_y = ytop;
+    }
+    __syncthreads();
+    const int valid = sh_i[0];
+    if (!valid) {
+        if (threadIdx.x == 0) ws.cand_valid[(int64_t)f * ws.maxcand + k] = 0;
+        return;
+    }
+    const int sy0 = sh_i[1], sy1 = sh_i[2], sx0 = sh_i[3], sx1 = sh_i[4];
+    const int sw = max(sx1 - sx0, 0), shh = max(sy1 - sy0, 0);
+    const int64_t cnt = (int64_t)sw * shh;
+    double acc = 0.0;
+    const float* P = ws.prob + (int64_t)f * ws.P;
+    for (int64_t t = threadIdx.x; t < cnt; t += 64) {
+        const int yy = sy0 + (int)(t / sw), xx = sx0 + (int)(t % sw);
+        acc += (double)P[(int64_t)yy * ws.w + xx];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (threadIdx.x == 0) {
+        rec.confidence = cnt > 0 ? (float)(acc / (double)cnt) : __builtin_nanf("");
+        ws.cand_rec[(int64_t)f * ws.maxcand + k] = rec;
+        ws.cand_valid[(int64_t)f * ws.maxcand + k] = 1;
+    }
+}
+
+// one block per frame: compact the surviving candidates, reverse raster order
+__global__ __launch_bounds__(SCAN_THREADS) void pp_emit(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    const int f = blockIdx.x;
+    const int nc = ws.ncand[f];
+    const int* valid = ws.cand_valid + (int64_t)f * ws.maxcand;
+    const int chunk = (nc + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(threadIdx.x * chunk, nc), hi = min(lo + chunk, nc);
+    int cnt = 0;
+    for (int k = lo; k < hi; ++k) cnt += valid[k];
+    int total;
+    int base = block_exclusive_scan(cnt, sh, &total);
+    for (int k = lo; k < hi; ++k)
+        if (valid[k]) {
+            const int dst = total - 1 - base;
+            if (dst < ws.max_out) ws.out[(int64_t)f * ws.max_out + dst] = ws.cand_rec[(int64_t)f * ws.maxcand + k];
+            base++;
+        }
+    if (threadIdx.x == 0) ws.out_count[f] = total;
+}
+
+}  // namespace
+
+struct vtd_postproc {
+    int max_batch = 0, h = 0, w = 0, max_out = 0;
+    PostWs ws;
+    void* blocks[16];
+    int nblocks = 0;
+    int *orig_w_dev = nullptr, *orig_h_dev = nullptr;
+};
+
+static int pp_alloc(vtd_postproc* pp, void** out, size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (bytes + 255) & ~size_t(255));
+    if (e != hipSuccess) return -(int)e;
+    pp->blocks[pp->nblocks++] = p;
+    *out = p;
+    return 0;
+}
+
+extern "C" {
+
+int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_postproc** out) {
+    if (!out || max_batch <= 0 || map_h <= 0 || map_w <= 0 || max_out <= 0 || (int64_t)map_h * map_w > (1 << 26)) return -1100;
+    auto* pp = new vtd_postproc();
+    pp->max_batch = max_batch; pp->h = map_h; pp->w = map_w; pp->max_out = max_out;
+    PostWs& ws = pp->ws;
+    const int64_t P = (int64_t)map_h * map_w;
+    ws.h = map_h; ws.w = map_w; ws.P = (int)P;
+    ws.maxc = ((map_h + 1) / 2) * ((map_w + 1) / 2) + 1;
+    ws.maxcand = (int)(P / 100) + 1;
+    ws.max_out = max_out;
+    const int64_t B = max_batch;
+    int rc = 0;
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.label, B * (P + 1) * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.flags, B * P);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.compid, B * P * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.ncomp, B * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.area2, B * ws.maxc * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.bbox, B * ws.maxc * 16);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowoff, B * ws.maxc * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.candlist, B * ws.maxcand * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.ncand, B * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowmin, B * P * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowmax, B * P * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.hull, B * (P + 8) * 48);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.cand_rec, B * ws.maxcand * sizeof(vtd_detection));
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.cand_valid, B * ws.maxcand * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&pp->orig_w_dev, B * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&pp->orig_h_dev, B * 4);
+    if (rc) {
+        for (int i = 0; i < pp->nblocks; ++i) (void)hipFree(pp->blocks[i]);
+        delete pp;
+        return rc;
+    }
+    *out = pp;
+    return 0;
+}
+
+void vtd_postproc_destroy(vtd_postproc* pp) {
+    if (!pp) return;
+    for (int i = 0; i < pp->nblocks; ++i) (void)hipFree(pp->blocks[i]);
+    delete pp;
+}
+
+int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
+                     float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream) {
+    if (!pp || !prob_dev || !orig_w_host || !orig_h_host || !out_dev || !counts_dev) return -1100;
+    if (n <= 0 || n > pp->max_batch) return -1105;
+    for (int i = 0; i < n; ++i)
+        if (orig_w_host[i] <= 0 || orig_h_host[i] <= 0) return -1100;
+    hipStream_t s = (hipStream_t)stream;
+    VTD_HIP_CHECK(hipMemcpyAsync(pp->orig_w_dev, orig_w_host, n * 4, hipMemcpyHostToDevice, s));
+    VTD_HIP_CHECK(hipMemcpyAsync(pp->orig_h_dev, orig_h_host, n * 4, hipMemcpyHostToDevice, s));
+    PostWs ws = pp->ws;
+    ws.prob = prob_dev; ws.n = n; ws.thr = threshold;
+    ws.orig_w = pp->orig_w_dev; ws.orig_h = pp->orig_h_dev;
+    ws.out = out_dev; ws.out_count = counts_dev;
+    const int64_t total = (int64_t)n * ws.P;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(pp_init, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_merge_fg_bg, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_classify, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_merge_inside, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_flatten, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_number_components, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+    hipLaunchKernelGGL(pp_stats, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+    hipLaunchKernelGGL(pp_row_extents, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_boxes, dim3(ws.maxcand, n), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(pp_emit, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+    return -(int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -121,3 +121,66 @@ class DetectorEngine:
             _native.check(self.lib.vtd_detector_read_tap(self.handle, name.encode(), n, out.ctypes.data, out.size, _stream_ptr()),
                           f"vtd_detector_read_tap({name})")
         return out
+
+
+class PostProcessor:
+    """``TextDetector._post_process`` on the GPU for a batch of probability maps (vtd_postproc_*)."""
+
+    def __init__(self, max_batch, map_h=640, map_w=640, max_out=1024):
+        self.lib = _native.require()
+        self.max_batch, self.h, self.w, self.max_out = max_batch, map_h, map_w, max_out
+        self.lock = threading.Lock()
+        h = C.c_void_p()
+        _native.check(self.lib.vtd_postproc_create(max_batch, map_h, map_w, max_out, C.byref(h)), "vtd_postproc_create")
+        self.handle = h
+        self.records = torch.empty((max_batch, max_out, 16), dtype=torch.int32, device="cuda")
+        self.counts = torch.empty((max_batch,), dtype=torch.int32, device="cuda")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vtd_postproc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_device(self, prob, orig_w, orig_h, threshold):
+        """Enqueue only; returns (records[n,max_out,16] int32 view, counts[n]) device tensors."""
+        n = prob.shape[0]
+        if prob.dtype != torch.float32 or not prob.is_cuda or tuple(prob.shape[-2:]) != (self.h, self.w):
+            raise ValueError("probability maps must be float32 cuda tensors of the workspace's map size")
+        prob = prob.reshape(n, self.h, self.w).contiguous()
+        ow = np.ascontiguousarray(orig_w, dtype=np.int32)
+        oh = np.ascontiguousarray(orig_h, dtype=np.int32)
+        _native.check(self.lib.vtd_postproc_run(self.handle, C.c_void_p(prob.data_ptr()), n, ow.ctypes.data, oh.ctypes.data,
+                                                float(threshold), C.c_void_p(self.records.data_ptr()),
+                                                C.c_void_p(self.counts.data_ptr()), _stream_ptr()), "vtd_postproc_run")
+        self._keep = (prob, ow, oh)
+        return self.records[:n], self.counts[:n]
+
+    def run(self, prob, orig_w, orig_h, threshold, debug=False):
+        with self.lock:
+            rec, cnt = self.run_device(prob, orig_w, orig_h, threshold)
+            cnt = cnt.cpu().numpy()
+            kmax = int(min(cnt.max(initial=0), self.max_out))
+            rec = rec[:, :kmax].cpu().numpy() if kmax else np.zeros((len(cnt), 0, 16), np.int32)
+        return [records_to_dicts(rec[i, :min(int(cnt[i]), self.max_out)], debug) for i in range(len(cnt))]
+
+
+def records_to_dicts(rec, debug=False):
+    """vtd_detection records -> the reference's detection dicts (text_detector.py:172-176): plain Python ints/floats."""
+    out = []
+    conf = rec[:, 12].copy().view(np.float32) if len(rec) else []
+    area = rec[:, 13].copy().view(np.float32) if len(rec) else []
+    for j in range(len(rec)):
+        r = rec[j]
+        d = {"bbox": [int(v) for v in r[0:4]], "confidence": float(conf[j]),
+             "polygon": [[int(r[4 + 2 * q]), int(r[5 + 2 * q])] for q in range(4)]}
+        if debug:
+            d["_area"] = float(area[j])
+            d["_first"] = (int(r[14]), int(r[15]))
+        out.append(d)
+    return out
