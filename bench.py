@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Throughput bench for the MI355X text-detection hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+fused preprocess (BGR uint8 720p -> 640x640 fp16) -> DBNet-ResNet18 (fp16 MFMA) -> post-process to boxes
+[-> crop + CRNN + CTC decode when --workload full].  Workload at N=1 = BASELINE.json configs[1]
+("Batch=32 720p frames, DBNet detector only, 1xMI355X fp16"); frames and "margin" weights as SURVEY.md 8d.
+For N>1 every rank runs its own 32 frames (weak scaling, frames shard with no data-path collective); the
+only exchange is the gather of detection records to every rank (RCCL all_gather of a small padded block).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
+implicit-GEMM convolution, timed with HIP events on its launch stream across the timed region) and
+`cpu_baseline` (the CPU oracle timed on this host on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "video-text-detection-system_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--backbone", default="resnet18")
+    ap.add_argument("--workload", default="detector", choices=["detector"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
+    ap.add_argument("--layers-out", default=None, help="write the per-launch table as JSON to this path")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    from vtd_amd import synth, weights
+    from vtd_amd.engine import DetectorEngine, DeviceFrames, PostProcessor, detector_profile
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank if torch.cuda.device_count() > 1 else 0)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
+
+    B, H, W = args.batch, args.height, args.width
+    frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
+    dev_frames = DeviceFrames(frames)
+    sd = weights.margin_detector_state_dict(args.backbone, 0)
+    eng = DetectorEngine(args.backbone, sd, max_batch=B)
+    MAX_DET = 64
+    pp = PostProcessor(B, 640, 640, max_out=MAX_DET)
+    prob = torch.empty((B, 1, 640, 640), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world, B, MAX_DET, 16), dtype=torch.int32, device="cuda") if world > 1 else None
+    gathered_cnt = torch.empty((world, B), dtype=torch.int32, device="cuda") if world > 1 else None
+    import ctypes as C
+    from vtd_amd import _native
+    lib = eng.lib
+
+    def step():
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _native.check(lib.vtd_detector_preprocess(eng.handle, C.c_void_p(dev_frames.tensor.data_ptr()), B, H, W, s))
+        _native.check(lib.vtd_detector_forward(eng.handle, B, C.c_void_p(prob.data_ptr()), None, s))
+        rec, cnt = pp.run_device(prob, [W] * B, [H] * B, 0.5)
+        if world > 1:  # the one exchange step of the path: detections of every rank to every rank
+            dist.all_gather_into_tensor(gathered, rec.contiguous())
+            dist.all_gather_into_tensor(gathered_cnt, cnt.contiguous())
+        return rec, cnt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_profile:
+        lib.vtd_detector_set_profiling(eng.handle, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec, cnt = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- sanity: the timed path produced detections (not part of the timed region)
+    counts = cnt.cpu().numpy()
+    n_det = int(counts.sum())
+
+    roofline = None
+    layer_rows = []
+    if not args.no_profile:
+        prof = detector_profile(eng)
+        lib.vtd_detector_set_profiling(eng.handle, 0)
+        groups = {}
+        for name, ms, calls, macs in prof:
+            layer_rows.append({"launch": name, "ms_total": ms, "calls": calls, "gmac_total": macs / 1e9,
+                               "tflops": (2 * macs / (ms * 1e-3) / 1e12) if ms > 0 and macs > 0 else None})
+            if name.startswith("conv_igemm"):
+                key = name.split(">")[0] + ">"
+                g = groups.setdefault(key, [0.0, 0, 0.0])
+                g[0] += ms
+                g[1] += calls
+                g[2] += macs
+        key = max(groups, key=lambda k: groups[k][0])
+        ms, calls, macs = groups[key]
+        achieved = 2 * macs / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
+                    "algorithmic_gflop_per_launch": round(2 * macs / calls / 1e9, 3),
+                    "all_conv_tflops": round(sum(2 * g[2] for g in groups.values()) / (sum(g[0] for g in groups.values()) * 1e-3) / 1e12, 2),
+                    "conv_share_of_step": round(sum(g[0] for g in groups.values()) / (elapsed * 1e3), 3)}
+        if args.layers_out and rank == 0:
+            with open(args.layers_out, "w") as f:
+                json.dump(layer_rows, f, indent=1)
+
+    cpu_baseline = None
+    if rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
+        from oracle import pipeline as opipe
+        # the 1-GPU box grants a 16-CPU share of a much larger host: more threads than that only thrash
+        ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VTD_CPU_CORES", "16")))
+        torch.set_num_threads(ncores)
+        opipe.detect(frames[0], sd, args.backbone, 0.5)  # warm-up (oneDNN primitive creation)
+        done, t_cpu = 0, time.perf_counter()
+        while done < B and time.perf_counter() - t_cpu < args.cpu_seconds:
+            opipe.detect(frames[done], sd, args.backbone, 0.5)
+            done += 1
+        dt = time.perf_counter() - t_cpu
+        cpu_baseline = {"value": round(done / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"{done} of the {B} {H}p frames, one at a time (preprocess + DBNet-{args.backbone} fp32 torch CPU + C post-process)"}
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        out = {
+            "metric": "frames/sec (detect+recognize) @720p, 1/2/4/8 MI355X; box IoU vs CPU ref",
+            "value": round(total_frames / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), 1xMI355X fp16"
+                       if args.workload == "detector" else "full", "global_batch": world * B, "frame": [H, W],
+                       "backbone": args.backbone, "parallelism": f"frames sharded over {world} rank(s)",
+                       "detections_last_step_rank0": n_det},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

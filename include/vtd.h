@@ -72,6 +72,14 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
 int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_out, int64_t capacity, vtd_stream stream);
 /* Algorithmic live work of one frame through this detector, in MACs (for roofline accounting). */
 int64_t vtd_detector_macs_per_frame(const vtd_detector* d);
+/* Per-launch HIP-event timing on the launch stream (bench.py's roofline leg).  set_profiling(1) resets the
+ * accumulators; while enabled every vtd_detector_forward brackets each of its launches with events.
+ * get_profile resolves pending events (synchronises the stream) and returns, for launch slot op_index in
+ * [0, vtd_detector_num_ops), a description, the accumulated milliseconds, launch count and algorithmic MACs. */
+int vtd_detector_set_profiling(vtd_detector* d, int enable);
+int vtd_detector_num_ops(const vtd_detector* d);
+int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name_cap, double* total_ms, int64_t* calls,
+                             double* total_macs, vtd_stream stream);
 
 /* ---- post-process: TextDetector._post_process (text_detector.py:143-178) ------------------------ */
 /* Workspace for maps of map_h x map_w (the reference hard-codes 640 in the bbox arithmetic but its tests feed

@@ -35,6 +35,7 @@ struct PostWs {
     uint8_t* flags;    // [n][P]  bit0 foreground, bit1 inside (not frame background)
     int* compid;       // [n][P]  valid at component roots
     int* ncomp;        // [n]
+    int* slice_count;  // [n][ceil(P/64)] roots per 64-pixel slice, then their exclusive prefix
     int maxc;          // capacity of the per-component arrays
     int* area2;        // [n][maxc]  2 * contour area
     int* bbox;         // [n][maxc][4] xmin,xmax,ymin,ymax
@@ -79,22 +80,41 @@ __device__ __forceinline__ void uf_unite(int* L, int a, int b) {
     }
 }
 
-__global__ void pp_init(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        const int y = pix / ws.w, x = pix - y * ws.w;
-        const bool fg = ws.prob[i] > ws.thr;
-        const bool border = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        L[pix + 1] = (!fg && border) ? 0 : pix + 1;
-        if (pix == 0) L[0] = 0;
-        ws.flags[i] = fg ? 1 : 0;
-        ws.rowmin[i] = 0x7fffffff;
-        ws.rowmax[i] = -1;
+// ---- stage 1: threshold + horizontal runs.  One wave owns 64 consecutive pixels of one row: a ballot of the
+// foreground bit gives every lane the start of its same-class run inside the segment, which becomes its
+// initial union-find parent.  Horizontal connectivity therefore costs no atomics at all, and the (usually
+// huge) frame background collapses to one run per row segment instead of one node per pixel.
+__global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int segs = (ws.w + 63) >> 6;
+    const int64_t total = (int64_t)ws.n * ws.h * segs;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wi = wave0; wi < total; wi += nwaves) {
+        const int f = (int)(wi / ((int64_t)ws.h * segs));
+        const int rem = (int)(wi - (int64_t)f * ws.h * segs);
+        const int y = rem / segs, seg = rem - y * segs;
+        const int x = seg * 64 + lane;
+        const bool valid = x < ws.w;
+        const int pix = y * ws.w + x;
+        const bool fg = valid && (ws.prob[(int64_t)f * ws.P + pix] > ws.thr);
+        const unsigned long long m = __ballot(fg);
+        const unsigned long long same = fg ? m : ~m;
+        const unsigned long long below = lane ? (~same & ((1ull << lane) - 1ull)) : 0ull;
+        const int start = below ? 64 - __clzll((long long)below) : 0;
+        if (valid) {
+            int* L = ws.label + (int64_t)f * (ws.P + 1);
+            int parent = y * ws.w + seg * 64 + start + 1;
+            // background on the frame's border belongs to the (virtual) outside: hang it on the sentinel
+            if (!fg && (y == 0 || y == ws.h - 1 || x == 0)) parent = 0;
+            L[pix + 1] = parent;
+            ws.flags[(int64_t)f * ws.P + pix] = fg ? 1 : 0;
+        }
+        if (wi == (int64_t)f * ws.h * segs && lane == 0) ws.label[(int64_t)f * (ws.P + 1)] = 0;
     }
 }
 
+// ---- stage 2: join runs.  Only the first column of every run-to-run contact issues a union.
 __global__ void pp_merge_fg_bg(const PostWs ws) {
     const int64_t total = (int64_t)ws.n * ws.P;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -103,11 +123,21 @@ __global__ void pp_merge_fg_bg(const PostWs ws) {
         const uint8_t* F = ws.flags + (int64_t)f * ws.P;
         int* L = ws.label + (int64_t)f * (ws.P + 1);
         const int me = F[pix] & 1;
-        if (x > 0 && (F[pix - 1] & 1) == me) uf_unite(L, pix + 1, pix);
-        if (y > 0 && (F[pix - ws.w] & 1) == me) uf_unite(L, pix + 1, pix - ws.w + 1);
-        if (me && y > 0) {  // foreground is 8-connected: add the two diagonals
-            if (x > 0 && (F[pix - ws.w - 1] & 1)) uf_unite(L, pix + 1, pix - ws.w);
-            if (x < ws.w - 1 && (F[pix - ws.w + 1] & 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
+        const int W = x > 0 ? (F[pix - 1] & 1) : -1;
+        if ((x & 63) == 0 && W == me) uf_unite(L, pix + 1, pix);  // run continues across a 64-pixel segment seam
+        if (!me && x == ws.w - 1) uf_unite(L, pix + 1, 0);          // background touching the right frame edge
+        if (y == 0) continue;
+        const int N = F[pix - ws.w] & 1;
+        const int NW = x > 0 ? (F[pix - ws.w - 1] & 1) : -1;
+        if (me) {  // foreground: 8-connected
+            if (N) {
+                if (!(W == 1 && NW == 1)) uf_unite(L, pix + 1, pix - ws.w + 1);
+            } else {
+                if (NW == 1 && W != 1) uf_unite(L, pix + 1, pix - ws.w);
+                if (x < ws.w - 1 && (F[pix - ws.w + 1] & 1) && !(F[pix + 1] & 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
+            }
+        } else if (!N) {  // background: 4-connected
+            if (!(W == 0 && NW == 0)) uf_unite(L, pix + 1, pix - ws.w + 1);
         }
     }
 }
@@ -124,30 +154,46 @@ __global__ void pp_classify(const PostWs ws) {
     }
 }
 
+// ---- stage 3: filled components = foreground + holes + islands.  Same-class neighbours are already joined
+// (diagonal hole pixels always share a 4-connected or foreground bridge), so only class changes need unions.
 __global__ void pp_merge_inside(const PostWs ws) {
     const int64_t total = (int64_t)ws.n * ws.P;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
         const uint8_t* F = ws.flags + (int64_t)f * ws.P;
-        if (!(F[pix] & 2)) continue;
+        const int me = F[pix];
+        if (!(me & 2)) continue;
         const int y = pix / ws.w, x = pix - y * ws.w;
         int* L = ws.label + (int64_t)f * (ws.P + 1);
-        if (x > 0 && (F[pix - 1] & 2)) uf_unite(L, pix + 1, pix);
+        auto other = [&](int q) { const int v = F[q]; return (v & 2) && ((v ^ me) & 1); };
+        if (x > 0 && other(pix - 1)) uf_unite(L, pix + 1, pix);
         if (y > 0) {
-            if (F[pix - ws.w] & 2) uf_unite(L, pix + 1, pix - ws.w + 1);
-            if (x > 0 && (F[pix - ws.w - 1] & 2)) uf_unite(L, pix + 1, pix - ws.w);
-            if (x < ws.w - 1 && (F[pix - ws.w + 1] & 2)) uf_unite(L, pix + 1, pix - ws.w + 2);
+            if (other(pix - ws.w)) uf_unite(L, pix + 1, pix - ws.w + 1);
+            if (x > 0 && other(pix - ws.w - 1)) uf_unite(L, pix + 1, pix - ws.w);
+            if (x < ws.w - 1 && other(pix - ws.w + 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
         }
     }
 }
 
-__global__ void pp_flatten(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        if (!(ws.flags[i] & 2)) continue;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        L[pix + 1] = uf_find(L, pix + 1);
+// ---- stage 4: flatten + count component roots per 64-pixel wave slice (coalesced)
+__global__ __launch_bounds__(256) void pp_flatten_count(const PostWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int slices = (ws.P + 63) >> 6;
+    const int64_t total = (int64_t)ws.n * slices;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wi = wave0; wi < total; wi += nwaves) {
+        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
+        const int pix = sl * 64 + lane;
+        bool root = false;
+        if (pix < ws.P && (ws.flags[(int64_t)f * ws.P + pix] & 2)) {
+            int* L = ws.label + (int64_t)f * (ws.P + 1);
+            const int r = uf_find(L, pix + 1);
+            L[pix + 1] = r;
+            root = r == pix + 1;
+        }
+        const unsigned long long m = __ballot(root);
+        if (lane == 0) ws.slice_count[(int64_t)f * slices + sl] = __popcll(m);
     }
 }
 
@@ -169,21 +215,23 @@ __device__ int block_exclusive_scan(int v, int* sh /* [2*SCAN_THREADS] */, int* 
     return incl - v;
 }
 
-// one block per frame: number the components by raster order of their root (= raster-first pixel)
-__global__ __launch_bounds__(SCAN_THREADS) void pp_number_components(const PostWs ws) {
+// one block per frame: exclusive scan of the slice counts (raster order), reset the per-component accumulators
+__global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) {
     __shared__ int sh[2 * SCAN_THREADS];
     const int f = blockIdx.x;
-    const int* L = ws.label + (int64_t)f * (ws.P + 1);
-    const uint8_t* F = ws.flags + (int64_t)f * ws.P;
-    int* cid = ws.compid + (int64_t)f * ws.P;
-    const int chunk = (ws.P + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int lo = threadIdx.x * chunk, hi = min(lo + chunk, ws.P);
-    int cnt = 0;
-    for (int p = lo; p < hi; ++p) cnt += ((F[p] & 2) && L[p + 1] == p + 1) ? 1 : 0;
+    const int slices = (ws.P + 63) >> 6;
+    int* cnt = ws.slice_count + (int64_t)f * slices;
+    const int chunk = (slices + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(threadIdx.x * chunk, slices), hi = min(lo + chunk, slices);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
     int total;
-    int base = block_exclusive_scan(cnt, sh, &total);
-    for (int p = lo; p < hi; ++p)
-        if ((F[p] & 2) && L[p + 1] == p + 1) cid[p] = base++;
+    int base = block_exclusive_scan(sum, sh, &total);
+    for (int i = lo; i < hi; ++i) {
+        const int c = cnt[i];
+        cnt[i] = base;
+        base += c;
+    }
     if (total > ws.maxc) total = ws.maxc;  // cannot happen: maxc bounds the number of 8-connected components
     if (threadIdx.x == 0) ws.ncomp[f] = total;
     for (int c = threadIdx.x; c < total; c += SCAN_THREADS) {
@@ -193,30 +241,90 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_number_components(const PostW
     }
 }
 
-__global__ void pp_stats(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        const int y = pix / ws.w, x = pix - y * ws.w;
+// number the components by raster order of their root (= raster-first pixel of the component)
+__global__ __launch_bounds__(256) void pp_number_components(const PostWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int slices = (ws.P + 63) >> 6;
+    const int64_t total = (int64_t)ws.n * slices;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wi = wave0; wi < total; wi += nwaves) {
+        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
+        const int pix = sl * 64 + lane;
+        const bool root = pix < ws.P && (ws.flags[(int64_t)f * ws.P + pix] & 2) &&
+                          ws.label[(int64_t)f * (ws.P + 1) + pix + 1] == pix + 1;
+        const unsigned long long m = __ballot(root);
+        if (root) ws.compid[(int64_t)f * ws.P + pix] = ws.slice_count[(int64_t)f * slices + sl] +
+                                                         __popcll(m & ((1ull << lane) - 1ull));
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
+// ---- stage 5: per-component contour area (lattice identity) and bounding box.  A wave's 64 consecutive pixels
+// nearly always belong to one or two components, so contributions are combined per component inside the wave and
+// one lane issues the atomics.
+__global__ __launch_bounds__(256) void pp_stats(const PostWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int slices = (ws.P + 63) >> 6;
+    const int64_t total = (int64_t)ws.n * slices;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wi = wave0; wi < total; wi += nwaves) {
+        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
+        const int pix = sl * 64 + lane;
         const uint8_t* F = ws.flags + (int64_t)f * ws.P;
         const int* L = ws.label + (int64_t)f * (ws.P + 1);
         const int* cid = ws.compid + (int64_t)f * ws.P;
-        const bool in00 = F[pix] & 2;
-        if (in00) {
-            const bool edge = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1 || !(F[pix - 1] & 2) || !(F[pix + 1] & 2) ||
-                              !(F[pix - ws.w] & 2) || !(F[pix + ws.w] & 2);
-            if (edge) {
-                int* bb = ws.bbox + ((int64_t)f * ws.maxc + cid[L[pix + 1] - 1]) * 4;
-                atomicMin(bb + 0, x); atomicMax(bb + 1, x); atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+        int comp = -1, add = 0, ex0 = 0x7fffffff, ex1 = -1, ey0 = 0x7fffffff, ey1 = -1;
+        if (pix < ws.P) {
+            const int y = pix / ws.w, x = pix - y * ws.w;
+            const bool in00 = F[pix] & 2;
+            int cnt = 0, any = -1;
+            if (x < ws.w - 1 && y < ws.h - 1) {
+                const bool in10 = F[pix + 1] & 2, in01 = F[pix + ws.w] & 2, in11 = F[pix + ws.w + 1] & 2;
+                cnt = (int)in00 + (int)in10 + (int)in01 + (int)in11;
+                any = in00 ? pix : pix + 1;  // with >= 3 of 4 set, one of the top two is set
             }
+            if (in00) {
+                comp = cid[L[pix + 1] - 1];
+                const bool edge = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1 || !(F[pix - 1] & 2) || !(F[pix + 1] & 2) ||
+                                  !(F[pix - ws.w] & 2) || !(F[pix + ws.w] & 2);
+                if (edge) { ex0 = ex1 = x; ey0 = ey1 = y; }
+            } else if (cnt >= 3) {
+                comp = cid[L[any + 1] - 1];
+            }
+            if (cnt >= 3) add = cnt == 4 ? 2 : 1;
         }
-        if (x < ws.w - 1 && y < ws.h - 1) {
-            const bool in10 = F[pix + 1] & 2, in01 = F[pix + ws.w] & 2, in11 = F[pix + ws.w + 1] & 2;
-            const int cnt = (int)in00 + (int)in10 + (int)in01 + (int)in11;
-            if (cnt >= 3) {
-                const int any = in00 ? pix : pix + 1;  // with >= 3 of 4 set one of the top two is set
-                atomicAdd(ws.area2 + (int64_t)f * ws.maxc + cid[L[any + 1] - 1], cnt == 4 ? 2 : 1);
+        bool pending = comp >= 0 && (add != 0 || ex1 >= 0);
+        unsigned long long pm = __ballot(pending);
+        while (pm) {
+            const int leader = __ffsll((long long)pm) - 1;
+            const int lc = __shfl(comp, leader);
+            const bool mine = pending && comp == lc;
+            const int s = wave_sum(mine ? add : 0);
+            const int a0 = wave_min(mine ? ex0 : 0x7fffffff), a1 = wave_max(mine ? ex1 : -1);
+            const int b0 = wave_min(mine ? ey0 : 0x7fffffff), b1 = wave_max(mine ? ey1 : -1);
+            if (lane == leader) {
+                if (s) atomicAdd(ws.area2 + (int64_t)f * ws.maxc + lc, s);
+                if (a1 >= 0) {
+                    int* bb = ws.bbox + ((int64_t)f * ws.maxc + lc) * 4;
+                    atomicMin(bb + 0, a0); atomicMax(bb + 1, a1); atomicMin(bb + 2, b0); atomicMax(bb + 3, b1);
+                }
             }
+            pending = pending && !mine;
+            pm = __ballot(pending);
         }
     }
 }
@@ -242,7 +350,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
             ws.candlist[(int64_t)f * ws.maxcand + base_c] = c;
             rowoff[c] = base_r;
             base_c++;
-            base_r += bbox[4 * c + 3] - bbox[4 * c + 2] + 1;
+            const int rows_c = bbox[4 * c + 3] - bbox[4 * c + 2] + 1;
+            for (int r = 0; r < rows_c; ++r) {
+                ws.rowmin[(int64_t)f * ws.P + base_r + r] = 0x7fffffff;
+                ws.rowmax[(int64_t)f * ws.P + base_r + r] = -1;
+            }
+            base_r += rows_c;
         } else {
             rowoff[c] = -1;
         }
@@ -364,9 +477,10 @@ __device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int 
 
 // one wave per candidate: lane 0 builds hull + calipers + box, all lanes average the probability slice
 __global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
-    const int f = blockIdx.y, k = blockIdx.x;
-    if (k >= ws.ncand[f]) return;
+    const int f = blockIdx.y;
     __shared__ int sh_i[8];
+  for (int k = blockIdx.x; k < ws.ncand[f]; k += gridDim.x) {
+    __syncthreads();
     const int c = ws.candlist[(int64_t)f * ws.maxcand + k];
     const int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
     const int ytop = bb[2], H = bb[3] - bb[2] + 1;
@@ -460,7 +574,7 @@ __global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
     const int valid = sh_i[0];
     if (!valid) {
         if (threadIdx.x == 0) ws.cand_valid[(int64_t)f * ws.maxcand + k] = 0;
-        return;
+        continue;
     }
     const int sy0 = sh_i[1], sy1 = sh_i[2], sx0 = sh_i[3], sx1 = sh_i[4];
     const int sw = max(sx1 - sx0, 0), shh = max(sy1 - sy0, 0);
@@ -477,6 +591,7 @@ __global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
         ws.cand_rec[(int64_t)f * ws.maxcand + k] = rec;
         ws.cand_valid[(int64_t)f * ws.maxcand + k] = 1;
     }
+  }
 }
 
 // one block per frame: compact the surviving candidates, reverse raster order
@@ -505,7 +620,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_emit(const PostWs ws) {
 struct vtd_postproc {
     int max_batch = 0, h = 0, w = 0, max_out = 0;
     PostWs ws;
-    void* blocks[16];
+    void* blocks[24];
     int nblocks = 0;
     int *orig_w_dev = nullptr, *orig_h_dev = nullptr;
 };
@@ -537,6 +652,7 @@ int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_po
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.flags, B * P);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.compid, B * P * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.ncomp, B * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.slice_count, B * ((P + 63) / 64) * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.area2, B * ws.maxc * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.bbox, B * ws.maxc * 16);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowoff, B * ws.maxc * 4);
@@ -579,16 +695,20 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     ws.out = out_dev; ws.out_count = counts_dev;
     const int64_t total = (int64_t)n * ws.P;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(pp_init, dim3(blocks), dim3(256), 0, s, ws);
+    const int64_t waves = (int64_t)n * ((ws.P + 63) / 64);
+    const int wblocks = (int)std::min<int64_t>((waves + 3) / 4, 256 * 16);
+    const int iblocks = (int)std::min<int64_t>(((int64_t)n * ws.h * ((ws.w + 63) / 64) + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_merge_fg_bg, dim3(blocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_classify, dim3(blocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_merge_inside, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_flatten, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_number_components, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
-    hipLaunchKernelGGL(pp_stats, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_flatten_count, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_scan_slices, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+    hipLaunchKernelGGL(pp_number_components, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     hipLaunchKernelGGL(pp_row_extents, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_boxes, dim3(ws.maxcand, n), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(64), 0, s, ws);
     hipLaunchKernelGGL(pp_emit, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     return -(int)hipGetLastError();
 }

@@ -166,6 +166,25 @@ struct vtd_detector {
     std::map<std::pair<int, int>, PreTables> pre;
     int64_t macs = 0;
     float* final_out[2] = {nullptr, nullptr};
+    // optional per-op HIP-event timing (bench / roofline accounting)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_spans;  // op index -> (start, stop)
+    std::vector<double> prof_ms;
+    std::vector<int64_t> prof_calls;
+    std::vector<double> prof_macs;  // algorithmic MACs issued per op (accumulated)
+    hipEvent_t take_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+    ~vtd_detector() {
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
 
     int alloc_tensor(TensorDesc& t) {
         void* p = nullptr;
@@ -615,16 +634,75 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
     if (n <= 0 || n > d->max_batch) return ERR_BATCH;
     hipStream_t s = (hipStream_t)stream;
     float* outs[2] = {prob_dev, thresh_dev};
-    for (const Op& o : d->ops) {
+    for (size_t oi = 0; oi < d->ops.size(); ++oi) {
+        const Op& o = d->ops[oi];
         int rc = 0;
         if (o.final_slot == 1 && !thresh_dev) continue;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (d->profiling) {
+            e0 = d->take_event();
+            e1 = d->take_event();
+            if (!e0 || !e1) return ERR_ARG;
+            VTD_HIP_CHECK(hipEventRecord(e0, s));
+        }
         switch (o.kind) {
             case Op::CONV: rc = launch_conv_op(o.conv, n, s); break;
             case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
             case Op::FINAL: rc = vtd_launch_final_convt_sigmoid(o.pin, o.fw, o.fbias, outs[o.final_slot], n, s); break;
         }
         if (rc) return rc;
+        if (d->profiling) {
+            VTD_HIP_CHECK(hipEventRecord(e1, s));
+            d->ev_spans.push_back({(int)oi, {e0, e1}});
+            d->prof_macs[oi] += (o.kind == Op::CONV) ? (double)o.conv.macs_per_image * n : 0.0;
+        }
     }
+    return 0;
+}
+
+int vtd_detector_set_profiling(vtd_detector* d, int enable) {
+    if (!d || !d->finalized) return ERR_ARG;
+    d->profiling = enable != 0;
+    d->ev_spans.clear();
+    d->ev_used = 0;
+    d->prof_ms.assign(d->ops.size(), 0.0);
+    d->prof_calls.assign(d->ops.size(), 0);
+    d->prof_macs.assign(d->ops.size(), 0.0);
+    return 0;
+}
+
+int vtd_detector_num_ops(const vtd_detector* d) { return d ? (int)d->ops.size() : 0; }
+
+int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name_cap, double* total_ms, int64_t* calls,
+                             double* total_macs, vtd_stream stream) {
+    if (!d || op_index < 0 || op_index >= (int)d->ops.size() || !name || name_cap < 32 || !total_ms || !calls || !total_macs)
+        return ERR_ARG;
+    if (!d->ev_spans.empty()) {  // resolve pending events once
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e;
+        for (auto& sp : d->ev_spans) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, sp.second.first, sp.second.second);
+            if (e != hipSuccess) return -(int)e;
+            d->prof_ms[sp.first] += ms;
+            d->prof_calls[sp.first] += 1;
+        }
+        d->ev_spans.clear();
+        d->ev_used = 0;
+    }
+    const Op& o = d->ops[op_index];
+    if (o.kind == Op::CONV) {
+        const ConvOp& c = o.conv;
+        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d", c.cout_pad % 128 == 0 ? "128,128" : "256,64",
+                      c.ho * c.wo, c.cout, c.K);
+    } else if (o.kind == Op::POOL) {
+        std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
+    } else {
+        std::snprintf(name, name_cap, "final_convt_sigmoid");
+    }
+    *total_ms = d->prof_ms[op_index];
+    *calls = d->prof_calls[op_index];
+    *total_macs = d->prof_macs[op_index];
     return 0;
 }
 

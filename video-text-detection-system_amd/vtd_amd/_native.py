@@ -36,6 +36,10 @@ SIGNATURES = {
     "vtd_detector_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vtd_detector_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vtd_detector_macs_per_frame": (C.c_int64, [C.c_void_p]),
+    "vtd_detector_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "vtd_detector_num_ops": (C.c_int, [C.c_void_p]),
+    "vtd_detector_get_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_double), C.c_void_p]),
     "vtd_postproc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_postproc_destroy": (None, [C.c_void_p]),
     "vtd_postproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,

@@ -184,3 +184,15 @@ def records_to_dicts(rec, debug=False):
             d["_first"] = (int(r[14]), int(r[15]))
         out.append(d)
     return out
+
+
+def detector_profile(engine):
+    """[(description, total_ms, calls, total_macs)] per launch slot of a DetectorEngine (after set_profiling(1))."""
+    lib, out = engine.lib, []
+    name = C.create_string_buffer(128)
+    ms, calls, macs = C.c_double(), C.c_int64(), C.c_double()
+    for i in range(lib.vtd_detector_num_ops(engine.handle)):
+        _native.check(lib.vtd_detector_get_profile(engine.handle, i, name, 128, C.byref(ms), C.byref(calls), C.byref(macs),
+                                                   _stream_ptr()), "vtd_detector_get_profile")
+        out.append((name.value.decode(), ms.value, calls.value, macs.value))
+    return out

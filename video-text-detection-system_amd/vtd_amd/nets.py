@@ -145,7 +145,7 @@ class DBNet(nn.Module):
         if self._engine is None or self._engine_version != self._version:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict())
+            self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict(), getattr(self, "_max_batch", None))
             self._engine_version = self._version
         return self._engine
 
