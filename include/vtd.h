@@ -92,6 +92,34 @@ void vtd_postproc_destroy(vtd_postproc* pp);
 int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
                      float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream);
 
+/* ---- recogniser: CRNN (app/ml/models/text_recognizer.py:12-37,114-167) --------------------------- */
+/* vocab_size = len(TextRecognizer.vocab) = 97 (text_recognizer.py:86-91); max_crops text regions per call. */
+int vtd_recognizer_create(int vocab_size, int max_crops, vtd_recognizer** out);
+void vtd_recognizer_destroy(vtd_recognizer* r);
+/* One tensor of the CRNN checkpoint (text_recognizer.py:95-96): "cnn.N.*", "rnn.weight_ih_l0[_reverse]", ...,
+ * "classifier.weight|bias"; float32, PyTorch memory order. */
+int vtd_recognizer_set_tensor(vtd_recognizer* r, const char* key, const float* host_data, int64_t numel);
+int vtd_recognizer_finalize(vtd_recognizer* r, vtd_stream stream);
+/* K6: for every box (frame, x1, y1, x2, y2) take frame[y1:y2, x1:x2] (pipeliine.py:121) out of frames_dev
+ * ([n_frames,H,W,3] uint8 BGR) and cv2.resize it to 128x32 (text_recognizer.py:118), then run conv1.  boxes_dev is
+ * [ncrops][5] int32 in device memory.  Boxes must lie inside the frame (invalid ones yield a zero crop). */
+int vtd_recognizer_crop_resize(vtd_recognizer* r, const uint8_t* frames_dev, int n_frames, int height, int width,
+                               const int32_t* boxes_dev, int ncrops, vtd_stream stream);
+/* Alternative input: the tensor the reference hands to CRNN.forward, [ncrops,3,32,128] float32 (text_recognizer.py:122). */
+int vtd_recognizer_set_input_nchw(vtd_recognizer* r, const float* x_dev, int ncrops, vtd_stream stream);
+/* CRNN.forward (text_recognizer.py:29-37) on the current input: logits_dev receives [ncrops,31,vocab] float32. */
+int vtd_recognizer_forward(vtd_recognizer* r, int ncrops, float* logits_dev, vtd_stream stream);
+/* Test taps as dense NCHW float32 on the host: "resized" ([n,32,128,3] uint8 values), "cnn" ([n,512,1,31]),
+ * "h0", "h1" ([n,512,1,31] LSTM layer outputs).  Synchronises the stream. */
+int vtd_recognizer_read_tap(vtd_recognizer* r, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream);
+int64_t vtd_recognizer_macs_per_crop(const vtd_recognizer* r);
+/* [softmax(dim=2) +] TextRecognizer._decode_prediction (text_recognizer.py:126,142-167) for n sequences of
+ * dense [T,V] rows (T <= 128): apply_softmax=1 takes logits and fuses the softmax, 0 takes probabilities as
+ * _decode_prediction itself does.  id2char_dev[V]: code point per class id or -1 for ids that emit nothing
+ * ('<blank>', '<unk>').  out_dev: [n][2+T] int32 = length, float confidence bits, then the code points. */
+int vtd_ctc_greedy_decode(const float* logits_dev, int n, int T, int V, const int32_t* id2char_dev, int blank_id, int apply_softmax,
+                          int32_t* out_dev, vtd_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""BASELINE config 3 at reduced batch: the full VideoTextPipeline (HIP detector + recogniser, batched fast path)
+against the CPU oracle's reference-shaped pipeline on the same synthetic 720p frames: identical boxes and
+polygons, identical strings (where the oracle's top-1 margin is >= 1e-2), confidences within 2e-3."""
+import asyncio
+import json
+
+import numpy as np
+import pytest
+
+from oracle import pipeline as opipe
+from vtd_amd import nets as mynets
+from vtd_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipeline(hip):
+    from vtd_amd.pipeline import VideoTextPipeline
+    p = VideoTextPipeline(use_transformer_ocr=False, backbone="resnet18", batch_size=8)
+    det_sd = weights.margin_detector_state_dict("resnet18", 0)
+    rec_sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    p.detector.model.load_state_dict(det_sd)
+    p.recognizer.model.load_state_dict(rec_sd)
+    return p, det_sd, rec_sd
+
+
+def _same(got, exp, rec_sd, frame):
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g["bbox"] == e["bbox"]
+        assert abs(g["detection_confidence"] - e["detection_confidence"]) <= 2e-3
+        x1, y1, x2, y2 = e["bbox"]
+        _, probs = opipe.recognize_batch([frame[y1:y2, x1:x2]], rec_sd, return_probs=True)
+        top2 = np.sort(probs[0], axis=1)[:, -2:]
+        if (top2[:, 1] - top2[:, 0]).min() >= 1e-2:
+            assert g["text"] == e["text"]
+            assert abs(g["recognition_confidence"] - e["recognition_confidence"]) <= 2e-3
+
+
+def test_frame_batch_fast_path_matches_oracle(pipeline):
+    p, det_sd, rec_sd = pipeline
+    frames = [synth.text_frame(100 + i)[0] for i in range(4)]
+    info = [(i, i / 10.0) for i in range(4)]
+    assert p._fast_path_ok(frames)
+    got = asyncio.run(p._process_frame_batch(frames, info, "/tmp"))
+    exp = opipe.process_frame_batch(frames, info, det_sd, "resnet18", rec_sd, 0.5)
+    json.dumps(got)
+    assert [g["frame_number"] for g in got] == [0, 1, 2, 3]
+    for g, e, f in zip(got, exp, frames):
+        assert g["timestamp"] == e["timestamp"]
+        _same(g["detections"], e["detections"], rec_sd, f)
+        for gd, ed in zip(g["detections"], e["detections"]):
+            assert gd["polygon"] == ed["polygon"]
+
+
+def test_single_frame_and_mixed_sizes_take_the_reference_shaped_route(pipeline):
+    p, det_sd, rec_sd = pipeline
+    frame = synth.text_frame(7, 1080, 1920)[0]
+    got = p.process_single_frame(frame)
+    exp = opipe.process_single_frame(frame, det_sd, "resnet18", rec_sd, 0.5)
+    _same(got["detections"], exp["detections"], rec_sd, frame)
+    assert all("polygon" not in d for d in got["detections"])
+    mixed = [synth.text_frame(1, 720, 1280)[0], synth.text_frame(2, 480, 640)[0]]
+    assert not p._fast_path_ok(mixed)
+    out = asyncio.run(p._process_frame_batch(mixed, [(0, 0.0), (1, 0.1)], "/tmp"))
+    for o, f in zip(out, mixed):
+        e = opipe.process_frame_batch([f], [(0, 0.0)], det_sd, "resnet18", rec_sd, 0.5)[0]
+        _same(o["detections"], e["detections"], rec_sd, f)
+
+
+def test_mock_seams_switch_off_the_fast_path(pipeline):
+    from unittest.mock import patch
+    p, _, _ = pipeline
+    frames = [synth.text_frame(100)[0]] * 2
+    with patch.object(p.detector, "detect") as det, patch.object(p.recognizer, "recognize") as rec:
+        det.return_value = [{"bbox": [50, 80, 200, 120], "confidence": 0.8}]
+        rec.return_value = {"text": "TEST TEXT", "confidence": 0.9}
+        assert not p._fast_path_ok(frames)
+        out = asyncio.run(p._process_frame_batch(frames, [(0, 0.0), (1, 0.1)], "/tmp"))
+        assert det.call_count == 2 and rec.call_count == 2
+        assert out[0]["detections"][0]["text"] == "TEST TEXT" and out[0]["detections"][0]["polygon"] == []

@@ -1,0 +1,120 @@
+"""Host logic of VideoTextPipeline on CPU with the reference's own mock seams: rows H1-H3 of SURVEY 8(a), pinned by
+tests/golden/pipeline_harness.json (produced by the reference's unmodified pipeliine.py).  No GPU: the pipeline
+object is built with __new__ + attribute injection exactly as the survey's recipe does for the reference."""
+import asyncio
+import json
+import os
+from concurrent.futures import ThreadPoolExecutor
+from unittest.mock import Mock
+
+import numpy as np
+import pytest
+
+from vtd_amd.pipeline import VideoTextPipeline
+
+
+@pytest.fixture
+def harness(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "pipeline_harness.json")))
+
+
+@pytest.fixture
+def pipe():
+    p = VideoTextPipeline.__new__(VideoTextPipeline)
+    p.confidence_threshold = 0.5
+    p.batch_size = 16
+    p.executor = ThreadPoolExecutor(max_workers=4)
+    p.detector = Mock()
+    p.recognizer = Mock()
+    return p
+
+
+DETS = [{"bbox": [50, 80, 200, 120], "confidence": 0.8, "polygon": [[50, 80], [200, 80], [200, 120], [50, 120]]},
+        {"bbox": [10, 10, 10, 40], "confidence": 0.7}]
+
+
+def test_h1_process_single_frame(pipe, harness):
+    pipe.detector.detect.return_value = DETS
+    pipe.recognizer.recognize.return_value = {"text": " TEST TEXT ", "confidence": 0.9}
+    frame = np.zeros((480, 640, 3), np.uint8)
+    assert pipe.process_single_frame(frame) == harness["H1"]
+    assert list(pipe.recognizer.recognize.call_args[0][0].shape) == harness["H1_crop_shape"]  # the zero-width crop is skipped
+    pipe.detector.detect.assert_called_once_with(frame, 0.5)
+    pipe.detector.detect.side_effect = Exception("boom")
+    assert pipe.process_single_frame(frame) == harness["H1_error"]
+    pipe.detector.detect.side_effect = None
+    pipe.detector.detect.return_value = []
+    assert pipe.process_single_frame(frame) == {"detections": []}
+
+
+def test_h2_process_frame_batch(pipe, harness):
+    frame = np.zeros((480, 640, 3), np.uint8)
+    pipe.detector.detect.return_value = DETS
+    pipe.recognizer.recognize.return_value = {"text": " TEST TEXT ", "confidence": 0.9}
+    got = asyncio.run(pipe._process_frame_batch([frame, frame], [(0, 0.0), (1, 0.1)], "/tmp"))
+    assert got == harness["H2"]
+    pipe.detector.detect.return_value = [{"bbox": [50, 80, 200, 120], "confidence": 0.8}]
+    assert asyncio.run(pipe._process_frame_batch([frame], [(5, 0.5)], "/tmp")) == harness["H2_no_polygon"]
+    pipe.detector.detect.return_value = []
+    assert asyncio.run(pipe._process_frame_batch([frame], [(6, 0.6)], "/tmp")) == harness["H2_no_detections"]
+
+
+def test_h3_generate_summary(pipe, harness):
+    got = pipe._generate_summary(harness["H3_input"], 2.0, 3)
+    exp = dict(harness["H3"])
+    assert set(got.pop("detected_texts")) == set(exp.pop("detected_texts"))
+    assert got == exp
+    assert pipe._generate_summary([], 0.0, 0) == harness["H3_empty"]
+    json.dumps(got)  # the summary goes through Celery's JSON serializer
+
+
+def test_process_video_loop_batches_progress_and_failure(pipe, tmp_path):
+    from vtd_amd.video import VideoProcessor
+    frames = np.zeros((90, 48, 64, 3), np.uint8)  # 90 frames @30 fps, the shape of tests/test_integration.py:17-35
+    path = str(tmp_path / "clip.npy")
+    np.save(path, frames)
+    pipe.video_processor = VideoProcessor()
+    pipe.batch_size = 4
+    pipe.detector.detect.return_value = [{"bbox": [5, 5, 40, 30], "confidence": 0.9, "polygon": []}]
+    pipe.recognizer.recognize.return_value = {"text": "HELLO WORLD", "confidence": 0.95}
+    calls = []
+
+    async def progress(p, done, total):
+        calls.append((p, done, total))
+
+    out = asyncio.run(pipe.process_video(path, str(tmp_path), progress))
+    assert out["status"] == "success"
+    assert out["video_info"] == {"fps": 30.0, "frame_count": 90, "width": 64, "height": 48, "duration": 3.0, "format": ".npy"}
+    assert len(out["results"]) == 30  # sampling rule: every int(30/10) = 3rd frame
+    assert [r["frame_number"] for r in out["results"]] == list(range(30))
+    assert abs(out["results"][1]["timestamp"] - 0.1) < 1e-9
+    assert out["summary"]["total_detections"] == 30 and out["summary"]["detected_texts"] == ["HELLO WORLD"]
+    assert calls and calls[0] == (4 / 90, 4, 90) and all(c[1] % 4 == 0 for c in calls)
+    json.dumps(out)
+    bad = asyncio.run(pipe.process_video(str(tmp_path / "missing.npy"), str(tmp_path)))
+    assert bad["status"] == "success" and bad["results"] == [] and bad["video_info"] == {}  # same as the reference: errors are logged
+    pipe.video_processor = Mock()
+    pipe.video_processor.get_video_info.side_effect = RuntimeError("decoder exploded")
+    failed = asyncio.run(pipe.process_video(path, str(tmp_path)))
+    assert failed == {"status": "failed", "error": "decoder exploded", "results": []}
+
+
+def test_product_has_no_cpu_fallback_and_overlay_imports():
+    """Without a GPU the model classes must refuse to construct (no silent CPU path)."""
+    import torch
+    from vtd_amd import _native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vtd_amd.detector import TextDetector
+    from vtd_amd.recognizer import TextRecognizer
+    with pytest.raises(_native.NativeError):
+        TextDetector()
+    with pytest.raises(_native.NativeError):
+        TextRecognizer(use_transformer=False)
+    with pytest.raises(_native.NativeError):
+        VideoTextPipeline(use_transformer_ocr=False)
+    import app.ml as overlay  # the names the Celery worker and the reference tests import
+    from app.ml.inference.pipeline import VideoTextPipeline as P2
+    from app.ml.models.text_detector import DBNet, TextDetector as T2
+    from app.ml.models.text_recognizer import CRNN, TextRecognizer as R2
+    assert P2 is VideoTextPipeline and T2 is TextDetector and R2 is TextRecognizer and overlay.DBNet is DBNet and overlay.CRNN is CRNN

@@ -475,23 +475,32 @@ __device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int 
     return (long long)(ax - ox) * (by - oy) - (long long)(ay - oy) * (bx - ox);
 }
 
-// one wave per candidate: lane 0 builds hull + calipers + box, all lanes average the probability slice
-__global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
+// one 256-thread workgroup per candidate: the row table is staged into LDS, thread 0 runs the (inherently
+// sequential) monotone chains + rotating calipers out of LDS, then all threads average the probability slice.
+constexpr int BOX_THREADS = 256;
+__global__ __launch_bounds__(BOX_THREADS) void pp_boxes(const PostWs ws, const int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) int box_lds[];  // [2h] row table + [12h] hull scratch when use_lds
     const int f = blockIdx.y;
     __shared__ int sh_i[8];
+    __shared__ double sh_acc[BOX_THREADS / 64];
   for (int k = blockIdx.x; k < ws.ncand[f]; k += gridDim.x) {
     __syncthreads();
     const int c = ws.candlist[(int64_t)f * ws.maxcand + k];
     const int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
     const int ytop = bb[2], H = bb[3] - bb[2] + 1;
     const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
+    const int* rmin = ws.rowmin + (int64_t)f * ws.P + off;
+    const int* rmax = ws.rowmax + (int64_t)f * ws.P + off;
+    int* st = ws.hull + ((int64_t)f * (ws.P + 8) + off) * 12;
+    if (use_lds) {
+        for (int r = threadIdx.x; r < H; r += BOX_THREADS) { box_lds[r] = rmin[r]; box_lds[ws.h + r] = rmax[r]; }
+        rmin = box_lds; rmax = box_lds + ws.h; st = box_lds + 2 * ws.h;
+        __syncthreads();
+    }
     vtd_detection rec;
     if (threadIdx.x == 0) {
-        const int* rmin = ws.rowmin + (int64_t)f * ws.P + off;
-        const int* rmax = ws.rowmax + (int64_t)f * ws.P + off;
-        // scratch: 12 words per table row of this candidate.  The chain stack holds <= 2H+1 points; the strict
+        // scratch `st`: 12 words per table row of this candidate.  The chain stack holds <= 2H+1 points; the strict
         // hull has n <= 2H vertices and is converted to float in place, followed by vect[n] and inv_len[n]: 5n <= 10H.
-        int* st = ws.hull + ((int64_t)f * (ws.P + 8) + off) * 12;
         int m = 0;
         auto push_chain = [&](int base, int px, int py) {
             while (m - base >= 2 && cross3(st[2 * (m - 2)], st[2 * (m - 2) + 1], st[2 * (m - 1)], st[2 * (m - 1) + 1], px, py) <= 0) m--;
@@ -581,12 +590,16 @@ __global__ __launch_bounds__(64) void pp_boxes(const PostWs ws) {
     const int64_t cnt = (int64_t)sw * shh;
     double acc = 0.0;
     const float* P = ws.prob + (int64_t)f * ws.P;
-    for (int64_t t = threadIdx.x; t < cnt; t += 64) {
+    for (int64_t t = threadIdx.x; t < cnt; t += BOX_THREADS) {
         const int yy = sy0 + (int)(t / sw), xx = sx0 + (int)(t % sw);
         acc += (double)P[(int64_t)yy * ws.w + xx];
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) sh_acc[threadIdx.x >> 6] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        acc = 0.0;
+        for (int i = 0; i < BOX_THREADS / 64; ++i) acc += sh_acc[i];
         rec.confidence = cnt > 0 ? (float)(acc / (double)cnt) : __builtin_nanf("");
         ws.cand_rec[(int64_t)f * ws.maxcand + k] = rec;
         ws.cand_valid[(int64_t)f * ws.maxcand + k] = 1;
@@ -708,7 +721,9 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     hipLaunchKernelGGL(pp_row_extents, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(64), 0, s, ws);
+    const size_t box_lds = (size_t)14 * ws.h * sizeof(int);
+    const int use_lds = box_lds <= 60 * 1024;
+    hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(BOX_THREADS), use_lds ? box_lds : 0, s, ws, use_lds);
     hipLaunchKernelGGL(pp_emit, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     return -(int)hipGetLastError();
 }

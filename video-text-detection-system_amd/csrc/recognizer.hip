@@ -1,0 +1,307 @@
+// CRNN recogniser stages for gfx950 that are not plain implicit-GEMM convolutions:
+//   K6  crop + cv2.resize(img,(128,32)) + /255            (app/ml/inference/pipeliine.py:121, text_recognizer.py:118-119)
+//   K7a conv1 3x3 (3->64) + BN + ReLU + maxpool 2x2 fused  (text_recognizer.py:17)
+//   K8  bidirectional LSTM recurrence: one 16-wave workgroup per 16 crops x direction, state in registers/LDS
+//                                                          (text_recognizer.py:26,34; nn.LSTM gate order i,f,g,o)
+//   K9  softmax + argmax + the reference's greedy CTC decode (text_recognizer.py:126,142-167)
+#include "../../include/vtd.h"
+#include "vtd_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ K6
+// One workgroup per crop.  8-bit bilinear exactly as OpenCV's fixed-point path: 11-bit coefficients,
+// horizontal pass in int, vertical combine ((b0*(h0>>4))>>16 + (b1*(h1>>4))>>16 + 2)>>2; an exact 2x2
+// decimation (256x64 source) takes the area-average route like cv::resize does.
+struct CropParams {
+    const uint8_t* frames;  // [n, H, W, 3] BGR
+    const int32_t* boxes;   // [ncrops][5] frame, x1, y1, x2, y2  (crop = frame[y1:y2, x1:x2])
+    uint8_t* out;           // [ncrops, 32, 128, 3]
+    int H, W, ncrops;
+};
+
+__device__ __forceinline__ void linear_coef(int ssize, int dsize, int d, int& ofs, int& c0, int& c1) {
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    ofs = s;
+    c0 = __float2int_rn((1.f - f) * 2048.f);
+    c1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(const CropParams p) {
+    const int crop = blockIdx.x;
+    const int32_t* b = p.boxes + crop * 5;
+    const int x1 = b[1], y1 = b[2], sw = b[3] - b[1], sh = b[4] - b[2];
+    uint8_t* dst = p.out + (int64_t)crop * 32 * 128 * 3;
+    if (sw <= 0 || sh <= 0 || b[0] < 0 || x1 < 0 || y1 < 0 || b[3] > p.W || b[4] > p.H) {  // never read outside the frame
+        for (int i = threadIdx.x; i < 32 * 128 * 3; i += 256) dst[i] = 0;
+        return;
+    }
+    const uint8_t* src = p.frames + ((int64_t)b[0] * p.H + y1) * p.W * 3 + (int64_t)x1 * 3;
+    const int64_t stride = (int64_t)p.W * 3;
+    const bool area = (sw == 256 && sh == 64);
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int dy = i >> 7, dx = i & 127;
+        if (area) {
+            const uint8_t* r0 = src + (int64_t)(2 * dy) * stride + (2 * dx) * 3;
+            const uint8_t* r1 = r0 + stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (uint8_t)((r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2);
+            continue;
+        }
+        int sx0, a0, a1, sy0, b0, b1;
+        linear_coef(sw, 128, dx, sx0, a0, a1);
+        linear_coef(sh, 32, dy, sy0, b0, b1);
+        const int sx1 = min(sx0 + 1, sw - 1), sy1 = min(sy0 + 1, sh - 1);
+        const uint8_t* r0 = src + (int64_t)sy0 * stride;
+        const uint8_t* r1 = src + (int64_t)sy1 * stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[sx0 * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+            const int h1 = r1[sx0 * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            dst[i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K7a
+// conv1 (K = 27) is far too thin for MFMA: fp32 FMAs, weights in LDS, the 2x2 max-pool fused in.
+// One workgroup = one pooled output row of one crop: 64 pooled pixels x 64 channels; thread = pooled pixel x 16 ch.
+struct Conv1Params {
+    const uint8_t* in_u8;   // [n,32,128,3] uint8 (scaled by 1/255 here) or NULL
+    const float* in_f32;    // [n,3,32,128] float32 (reference-format tensor) or NULL
+    const float* w;         // [64][27] BN-folded, k = (r*3+s)*3 + c
+    const float* bias;      // [64]
+    half_t* out;            // [n, 16+2, 64+2, 64] ring 1
+    int n;
+};
+
+__global__ __launch_bounds__(256) void crnn_conv1_pool_kernel(const Conv1Params p) {
+    __shared__ float wsh[64 * 27];
+    __shared__ float bsh[64];
+    __shared__ float tile[4][130][3];  // input rows 2*py-1 .. 2*py+2, columns -1..128, zero padded
+    const int crop = blockIdx.y, py = blockIdx.x;
+    for (int i = threadIdx.x; i < 64 * 27; i += 256) wsh[i] = p.w[i];
+    if (threadIdx.x < 64) bsh[threadIdx.x] = p.bias[threadIdx.x];
+    for (int i = threadIdx.x; i < 4 * 130 * 3; i += 256) {
+        const int c = i % 3, xx = (i / 3) % 130, r = i / (3 * 130);
+        const int y = 2 * py - 1 + r, x = xx - 1;
+        float v = 0.f;
+        if (y >= 0 && y < 32 && x >= 0 && x < 128) {
+            if (p.in_u8) v = (float)p.in_u8[(((int64_t)crop * 32 + y) * 128 + x) * 3 + c] / 255.0f;
+            else v = p.in_f32[(((int64_t)crop * 3 + c) * 32 + y) * 128 + x];
+        }
+        tile[r][xx][c] = v;
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    float best[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) best[j] = 0.f;  // post-ReLU values are >= 0
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        const int oy = sub >> 1, ox = 2 * px + (sub & 1);
+        float patch[27];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) patch[(r * 3 + s) * 3 + c] = tile[oy + r][ox + s][c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int ch = cg * 16 + j;
+            float acc = bsh[ch];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc += patch[k] * wsh[ch * 27 + k];
+            best[j] = fmaxf(best[j], acc);
+        }
+    }
+    half_t* o = p.out + (((int64_t)crop * 18 + py + 1) * 66 + px + 1) * 64 + cg * 16;
+    half8 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h0[j] = (half_t)best[j]; h1[j] = (half_t)best[8 + j]; }
+    *(half8*)o = h0;
+    *(half8*)(o + 8) = h1;
+}
+
+// ------------------------------------------------------------------------------------------------ K8
+// LSTM recurrence for one layer, both directions.  grid = (ceil(D/16), 2 directions), 1024 threads = 16 waves.
+// Wave w owns hidden units [16w, 16w+16) for all four gates, so the gate maths for a unit never crosses lanes.
+// Per step: h_{t-1} (16 crops x 256, fp16, LDS) is the MFMA B operand, W_hh rows are the A operand, the
+// accumulators start from the hoisted input GEMM x_t W_ih^T + b (fp32), the wave applies the gate
+// non-linearities to its own 16 units x 16 crops in registers (cell state never leaves registers), and
+// writes h_t back to LDS (next step's operand) and to HBM (next layer's input).  One barrier per step.
+struct LstmParams {
+    const float* xs;      // [D*T, 2048] fp32: columns dir*1024 + gate*256 + unit
+    const half_t* whh;    // [2][1024][256] fp16 (dir, gate*256+unit, k)
+    half_t* hout;         // [D, T, 512] fp16 (fwd | rev)
+    int D, T;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(-2.f * fabsf(x));
+    const float t = (1.f - e) / (1.f + e);
+    return x < 0.f ? -t : t;
+}
+
+__global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams p) {
+    constexpr int HROW = 264;  // 256 + 8 halves of padding: rows land on different LDS banks
+    __shared__ __attribute__((aligned(16))) half_t hbuf[2][16][HROW];
+    const int dir = blockIdx.y;
+    const int crop0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;          // hidden units [16wv, 16wv+16)
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // W_hh fragments (A operand): row = unit (lane&15), k = 32*kc + 8*(lane>>4) .. +8.  The whole W_hh of one
+    // direction is 512 KB -- exactly one CU's register file -- so it cannot stay resident next to the state;
+    // each step re-streams it from L2 (all workgroups of a direction read the same 512 KB, so it stays L2-hot).
+    const half_t* wlane = p.whh + (int64_t)dir * 1024 * 256 + (int64_t)(wv * 16 + fr) * 256 + fq * 8;
+
+    for (int i = threadIdx.x; i < 2 * 16 * HROW; i += 1024) (&hbuf[0][0][0])[i] = (half_t)0.f;
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};  // cell state of units 16wv + 4fq + j, crop crop0 + fr
+    __syncthreads();
+
+    const int crop = min(crop0 + fr, p.D - 1);
+    const bool live = crop0 + fr < p.D;
+    for (int step = 0; step < p.T; ++step) {
+        const int t = dir ? p.T - 1 - step : step;
+        const int cur = step & 1;
+        floatx4 acc[4];
+        const float* xrow = p.xs + ((int64_t)crop * p.T + t) * 2048 + dir * 1024 + wv * 16 + fq * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(xrow + g * 256);
+            acc[g] = floatx4{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const half8 hf = *(const half8*)(&hbuf[cur][fr][kc * 32 + fq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half8 wf = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hf, acc[g], 0, 0, 0);
+            }
+        }
+        half4 hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ig = sigmoidf_(acc[0][j]), fg = sigmoidf_(acc[1][j]), gg = tanhf_(acc[2][j]), og = sigmoidf_(acc[3][j]);
+            cst[j] = fg * cst[j] + ig * gg;
+            hv[j] = (half_t)(og * tanhf_(cst[j]));
+        }
+        *(half4*)(&hbuf[cur ^ 1][fr][wv * 16 + fq * 4]) = hv;
+        if (live) *(half4*)(p.hout + ((int64_t)crop * p.T + t) * 512 + dir * 256 + wv * 16 + fq * 4) = hv;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K9
+// One wave per sequence.  Row maxima / arg-maxima / softmax denominators by wave reduction, then lane 0
+// replays the reference's decode loop (blank does not reset prev, '<unk>' emits nothing but resets it,
+// confidence row = output length - 1).
+struct DecodeParams {
+    const float* logits;   // [n, T, ld] (first V columns valid)
+    const int32_t* id2char; // [V] code point or -1 (blank / unk / unmapped)
+    int32_t* out;          // [n][2 + T]: length, confidence bits (float), then `length` code points
+    int n, T, V, ld, blank;
+    int apply_softmax;     // 1: rows are logits (softmax(dim=2) fused, text_recognizer.py:126); 0: rows are probabilities
+};
+
+__global__ __launch_bounds__(64) void ctc_greedy_kernel(const DecodeParams p) {
+    __shared__ int s_idx[128];
+    __shared__ float s_pmax[128];
+    const int seq = blockIdx.x, lane = threadIdx.x;
+    for (int t = 0; t < p.T; ++t) {
+        const float* row = p.logits + ((int64_t)seq * p.T + t) * p.ld;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = lane; v < p.V; v += 64) {
+            const float x = row[v];
+            if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ob = __shfl_xor(best, d);
+            const int oi = __shfl_xor(bi, d);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        float pmax = best;
+        if (p.apply_softmax) {
+            float sum = 0.f;
+            for (int v = lane; v < p.V; v += 64) sum += expf(row[v] - best);
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+            pmax = 1.0f / sum;
+        }
+        if (lane == 0) { s_idx[t] = bi; s_pmax[t] = pmax; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int32_t* o = p.out + (int64_t)seq * (2 + p.T);
+        int len = 0, prev = -1;
+        double csum = 0.0;
+        for (int t = 0; t < p.T; ++t) {
+            const int k = s_idx[t];
+            if (k == p.blank || k == prev) continue;
+            const int ch = (k >= 0 && k < p.V) ? p.id2char[k] : -1;
+            if (ch >= 0) {
+                o[2 + len] = ch;
+                ++len;
+                csum += (double)s_pmax[len - 1];
+            }
+            prev = k;
+        }
+        o[0] = len;
+        const float conf = len ? (float)(csum / (double)len) : 0.f;
+        o[1] = __float_as_int(conf);
+    }
+}
+
+// dense copy of the first V columns of a [rows, ld] fp32 matrix
+__global__ void compact_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t rows, int V, int ld) {
+    const int64_t total = rows * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / V;
+        out[i] = in[r * ld + (i - r * V)];
+    }
+}
+
+}  // namespace
+
+int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s) {
+    CropParams p{frames, boxes, out, H, W, ncrops};
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(ncrops), dim3(256), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float* w, const float* bias, half_t* out, int n, hipStream_t s) {
+    Conv1Params p{in_u8, in_f32, w, bias, out, n};
+    hipLaunchKernelGGL(crnn_conv1_pool_kernel, dim3(16, n), dim3(256), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_lstm(const float* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s) {
+    LstmParams p{xs, whh, hout, D, T};
+    hipLaunchKernelGGL(lstm_recurrence_kernel, dim3((D + 15) / 16, 2), dim3(1024), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_ctc_greedy(const float* logits, int n, int T, int V, int ld, const int32_t* id2char, int blank, int apply_softmax,
+                          int32_t* out, hipStream_t s) {
+    if (T > 128 || T <= 0 || V <= 0) return -1040;
+    DecodeParams p{logits, id2char, out, n, T, V, ld, blank, apply_softmax};
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(n), dim3(64), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_compact_rows(const float* in, float* out, int64_t rows, int V, int ld, hipStream_t s) {
+    const int64_t total = rows * V;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, in, out, rows, V, ld);
+    return -(int)hipGetLastError();
+}

@@ -22,6 +22,13 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
                        hipStream_t stream);
 int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
 
+int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
+int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float* w, const float* bias, half_t* out, int n, hipStream_t s);
+int vtd_launch_lstm(const float* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s);
+int vtd_launch_ctc_greedy(const float* logits, int n, int T, int V, int ld, const int32_t* id2char, int blank, int apply_softmax,
+                          int32_t* out, hipStream_t s);
+int vtd_launch_compact_rows(const float* in, float* out, int64_t rows, int V, int ld, hipStream_t s);
+
 namespace vtd {
 
 enum : int {
@@ -154,12 +161,29 @@ struct PreTables {
 
 using namespace vtd;
 
-struct vtd_detector {
+namespace vtd {
+// what both model handles share: the ingested state dict and the device arena
+struct ModelBase {
+    StateDict sd;
+    DeviceArena arena;
+    int alloc_tensor(TensorDesc& t) {
+        void* p = nullptr;
+        int rc = arena.alloc(&p, (size_t)tensor_elems(t) * sizeof(half_t), true);
+        t.ptr = (half_t*)p;
+        return rc;
+    }
+    const std::vector<float>* get(const std::string& k, size_t numel) const {
+        auto it = sd.find(k);
+        if (it == sd.end() || it->second.size() != numel) return nullptr;
+        return &it->second;
+    }
+};
+}  // namespace vtd
+
+struct vtd_detector : vtd::ModelBase {
     std::string backbone;
     int max_batch = 0;
     bool finalized = false;
-    StateDict sd;
-    DeviceArena arena;
     std::vector<Op> ops;
     TensorDesc input;
     std::map<std::string, TensorDesc> taps;
@@ -185,18 +209,23 @@ struct vtd_detector {
     ~vtd_detector() {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
+};
 
-    int alloc_tensor(TensorDesc& t) {
-        void* p = nullptr;
-        int rc = arena.alloc(&p, (size_t)tensor_elems(t) * sizeof(half_t), true);
-        t.ptr = (half_t*)p;
-        return rc;
-    }
-    const std::vector<float>* get(const std::string& k, size_t numel) const {
-        auto it = sd.find(k);
-        if (it == sd.end() || it->second.size() != numel) return nullptr;
-        return &it->second;
-    }
+
+struct vtd_recognizer : vtd::ModelBase {
+    int vocab = 0, max_crops = 0;
+    bool finalized = false;
+    uint8_t* resized = nullptr;   // [D,32,128,3] K6 output
+    float *w1 = nullptr, *b1 = nullptr;  // conv1 fp32 [64][27], [64]
+    TensorDesc t1;
+    std::vector<Op> ops;          // conv2 .. conv7 with their pools
+    TensorDesc t7, h0, h1;
+    ConvOp xs_gemm[2], cls_gemm;
+    half_t* whh[2] = {nullptr, nullptr};
+    float* xs = nullptr;          // [D*31, 2048]
+    float* logits_pad = nullptr;  // [D*31, 128]
+    std::map<std::string, TensorDesc> taps;
+    int64_t macs = 0;
 };
 
 namespace vtd {
@@ -206,7 +235,7 @@ struct Fold {
 };
 
 // BatchNorm (eval) folded with an optional conv bias: y = (conv + b - mean) * g/sqrt(var+eps) + beta
-static int fold_bn(const vtd_detector* d, const std::string& bn, const std::string& bias_key, int cout, Fold& f) {
+static int fold_bn(const ModelBase* d, const std::string& bn, const std::string& bias_key, int cout, Fold& f) {
     f.scale.assign(cout, 1.0);
     f.shift.assign(cout, 0.0);
     const std::vector<float>* b = nullptr;
@@ -237,7 +266,7 @@ static int upload(DeviceArena& arena, const void* host, size_t bytes, void** dev
 }
 
 // Generic conv: weights [cout, cin, kh, kw]; K order (r, s, c) over the input's channel stride.
-static int build_conv(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey,
+static int build_conv(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey,
                       const Fold& f, int cin, int cout, int kh, int kw, int stride, int pad, int flags) {
     auto w = d->get(wkey, (size_t)cout * cin * kh * kw);
     if (!w) return ERR_MISSING_KEY;
@@ -274,7 +303,7 @@ static int build_conv(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorD
 
 // Stem: conv 7x7/s2/p3 on the ring-3 NHWC4 input.  K is laid out as 8 kernel rows x (8 taps x 4 ch):
 // one kernel row = 64 contiguous bytes of the input, rows 7 / taps 7 / channel 3 carry zero weights.
-static int build_stem(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f) {
+static int build_stem(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f) {
     auto w = d->get(wkey, (size_t)64 * 3 * 7 * 7);
     if (!w) return ERR_MISSING_KEY;
     if (in.c != 4 || in.ring != 3 || in.hp != in.h + 6 || in.wp != in.w + 6 || out.h != in.h / 2 || out.w != in.w / 2 || out.c != 64)
@@ -305,7 +334,7 @@ static int build_stem(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorD
 }
 
 // ConvTranspose2d(cin -> cout, k=2, s=2), weights [cin, cout, 2, 2]: GEMM with N = 4*cout and a pixel-shuffle store.
-static int build_convt(vtd_detector* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f,
+static int build_convt(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f,
                        int cin, int cout, int flags) {
     auto w = d->get(wkey, (size_t)cin * cout * 4);
     if (!w) return ERR_MISSING_KEY;
@@ -509,6 +538,45 @@ static int build_detector_graph(vtd_detector* d) {
     return 0;
 }
 
+// dense NCHW float32 host copy of a ring-padded NHWC fp16 tensor (test taps)
+static int read_tensor_nchw(const TensorDesc& t, int n, int creal, float* host_out, hipStream_t stream) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return -(int)e;
+    std::vector<half_t> tmp((size_t)n * t.hp * t.wp * t.c);
+    e = hipMemcpy(tmp.data(), t.ptr, tmp.size() * sizeof(half_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int)e;
+    for (int img = 0; img < n; ++img)
+        for (int c = 0; c < creal; ++c)
+            for (int y = 0; y < t.h; ++y)
+                for (int x = 0; x < t.w; ++x)
+                    host_out[(((size_t)img * creal + c) * t.h + y) * t.w + x] =
+                        (float)tmp[(((size_t)img * t.hp + y + t.ring) * t.wp + x + t.ring) * t.c + c];
+    return 0;
+}
+
+// Dense layer as a 1x1 convolution over a [rows,1,1,K]-shaped view: weights [N][K] (already in GEMM layout),
+// float32 row-major output with leading dimension ldc (LSTM input projections, classifier).
+static int build_linear(ModelBase* d, ConvOp& op, const TensorDesc& in, const std::vector<float>& W, const std::vector<float>& bias,
+                        int N, int K, float* out_f32, int ldc) {
+    if (in.c != K || (K & 63) || (int)W.size() != N * K || (int)bias.size() != N || (ldc & 3) || ldc < N) return ERR_GEOMETRY;
+    const int cout_pad = (N + 63) / 64 * 64;
+    std::vector<half_t> wp((size_t)cout_pad * K, (half_t)0.f);
+    for (size_t i = 0; i < (size_t)N * K; ++i) wp[i] = (half_t)W[i];
+    std::vector<float> b(cout_pad, 0.f);
+    for (int i = 0; i < N; ++i) b[i] = bias[i];
+    std::vector<int> ktab(K / 8);
+    for (int q = 0; q < K / 8; ++q) ktab[q] = q * 8;
+    int rc;
+    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, b.data(), b.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
+    op.in = in; op.out = in; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
+    op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = EPI_OUT_F32; op.ho = in.h; op.wo = in.w;
+    op.out_f32 = out_f32; op.ldc = ldc;
+    op.macs_per_image = (int64_t)in.h * in.w * N * K;
+    return 0;
+}
+
 static bool known_detector_key(const std::string& k) {
     return k.rfind("backbone.", 0) == 0 || k.rfind("fpn.", 0) == 0 || k.rfind("head.", 0) == 0;
 }
@@ -600,9 +668,6 @@ int vtd_detector_finalize(vtd_detector* d, vtd_stream stream) {
     if (d->finalized) return ERR_ARG;
     int rc = build_detector_graph(d);
     if (rc) return rc;
-    void* p = nullptr;
-    for (int i = 0; i < 2; ++i) d->final_out[i] = nullptr;
-    (void)p;
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return -(int)e;
     d->sd.clear();
@@ -715,20 +780,213 @@ int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_
     if (n <= 0 || n > t.n) return ERR_BATCH;
     const int creal = (std::string(name) == "input") ? 3 : t.c;
     if (capacity < (int64_t)n * creal * t.h * t.w) return ERR_CAPACITY;
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) return -(int)e;
-    std::vector<half_t> tmp((size_t)n * t.hp * t.wp * t.c);
-    e = hipMemcpy(tmp.data(), t.ptr, tmp.size() * sizeof(half_t), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return -(int)e;
-    for (int img = 0; img < n; ++img)
-        for (int c = 0; c < creal; ++c)
-            for (int y = 0; y < t.h; ++y)
-                for (int x = 0; x < t.w; ++x)
-                    host_out[(((size_t)img * creal + c) * t.h + y) * t.w + x] =
-                        (float)tmp[(((size_t)img * t.hp + y + t.ring) * t.wp + x + t.ring) * t.c + c];
-    return 0;
+    return read_tensor_nchw(t, n, creal, host_out, (hipStream_t)stream);
 }
 
 int64_t vtd_detector_macs_per_frame(const vtd_detector* d) { return d ? d->macs : 0; }
+
+}  // extern "C"
+
+// ================================================================================================ recognizer
+namespace vtd {
+
+static int build_recognizer_graph(vtd_recognizer* r) {
+    const int D = r->max_crops;
+    int rc;
+    auto new_tensor = [&](int h, int w, int c, int ring, TensorDesc& t) {
+        t = make_desc(D, h, w, c, ring, ring);
+        return r->alloc_tensor(t);
+    };
+    void* p = nullptr;
+    if ((rc = r->arena.alloc(&p, (size_t)D * 32 * 128 * 3, true))) return rc;
+    r->resized = (uint8_t*)p;
+    // conv1 (fp32 VALU kernel, pool fused)
+    {
+        Fold f;
+        if ((rc = fold_bn(r, "cnn.1", "cnn.0.bias", 64, f))) return rc;
+        auto w = r->get("cnn.0.weight", 64 * 3 * 3 * 3);
+        if (!w) return ERR_MISSING_KEY;
+        std::vector<float> wp(64 * 27), bp(64);
+        for (int co = 0; co < 64; ++co) {
+            bp[co] = (float)f.shift[co];
+            for (int c = 0; c < 3; ++c)
+                for (int rr = 0; rr < 3; ++rr)
+                    for (int ss = 0; ss < 3; ++ss)
+                        wp[co * 27 + (rr * 3 + ss) * 3 + c] = (float)((double)(*w)[((co * 3 + c) * 3 + rr) * 3 + ss] * f.scale[co]);
+        }
+        if ((rc = upload(r->arena, wp.data(), wp.size() * 4, (void**)&r->w1))) return rc;
+        if ((rc = upload(r->arena, bp.data(), bp.size() * 4, (void**)&r->b1))) return rc;
+        if ((rc = new_tensor(16, 64, 64, 1, r->t1))) return rc;
+        r->macs += (int64_t)32 * 128 * 64 * 27;
+    }
+    struct Spec { int conv, bn, cin, cout, k, pad, ph, pw; };
+    const Spec specs[6] = {{4, 5, 64, 128, 3, 1, 2, 2},  {8, 9, 128, 256, 3, 1, 0, 0},   {11, 12, 256, 256, 3, 1, 2, 1},
+                           {15, 16, 256, 512, 3, 1, 0, 0}, {18, 19, 512, 512, 3, 1, 2, 1}, {22, 23, 512, 512, 2, 0, 0, 0}};
+    TensorDesc x = r->t1;
+    for (const Spec& sp : specs) {
+        const int ho = x.h + 2 * sp.pad - sp.k + 1, wo = x.w + 2 * sp.pad - sp.k + 1;
+        TensorDesc y;
+        if ((rc = new_tensor(ho, wo, sp.cout, 1, y))) return rc;
+        Fold f;
+        const std::string ck = "cnn." + std::to_string(sp.conv), bk = "cnn." + std::to_string(sp.bn);
+        if ((rc = fold_bn(r, bk, ck + ".bias", sp.cout, f))) return rc;
+        Op o;
+        o.kind = Op::CONV;
+        if ((rc = build_conv(r, o.conv, x, y, ck + ".weight", f, sp.cin, sp.cout, sp.k, sp.k, 1, sp.pad, EPI_RELU))) return rc;
+        r->ops.push_back(o);
+        r->macs += o.conv.macs_per_image;
+        x = y;
+        if (sp.ph) {
+            TensorDesc z;
+            if ((rc = new_tensor(x.h / sp.ph, x.w / sp.pw, x.c, 1, z))) return rc;
+            Op po;
+            po.kind = Op::POOL;
+            po.pin = x; po.pout = z;
+            const int pk[6] = {sp.ph, sp.pw, sp.ph, sp.pw, 0, 0};
+            std::memcpy(po.pk, pk, sizeof(pk));
+            r->ops.push_back(po);
+            x = z;
+        }
+    }
+    if (x.h != 1 || x.w != 31 || x.c != 512) return ERR_GEOMETRY;
+    r->t7 = x;
+    r->taps["cnn"] = x;
+    const int T = 31;
+    // LSTM: hoisted input projections (both directions stacked -> N = 2048) + recurrent weights
+    if ((rc = r->arena.alloc(&p, (size_t)D * T * 2048 * 4, true))) return rc;
+    r->xs = (float*)p;
+    if ((rc = r->arena.alloc(&p, (size_t)D * T * 128 * 4, true))) return rc;
+    r->logits_pad = (float*)p;
+    r->h0 = make_desc(D, 1, T, 512, 0, 0);
+    r->h1 = make_desc(D, 1, T, 512, 0, 0);
+    if ((rc = r->alloc_tensor(r->h0)) || (rc = r->alloc_tensor(r->h1))) return rc;
+    r->taps["h0"] = r->h0;
+    r->taps["h1"] = r->h1;
+    for (int layer = 0; layer < 2; ++layer) {
+        std::vector<float> W((size_t)2048 * 512), B(2048);
+        std::vector<half_t> whh((size_t)2 * 1024 * 256);
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string suf = "_l" + std::to_string(layer) + (dir ? "_reverse" : "");
+            auto wih = r->get("rnn.weight_ih" + suf, (size_t)1024 * 512), wh = r->get("rnn.weight_hh" + suf, (size_t)1024 * 256);
+            auto bih = r->get("rnn.bias_ih" + suf, 1024), bhh = r->get("rnn.bias_hh" + suf, 1024);
+            if (!wih || !wh || !bih || !bhh) return ERR_MISSING_KEY;
+            std::copy(wih->begin(), wih->end(), W.begin() + (size_t)dir * 1024 * 512);
+            for (int i = 0; i < 1024; ++i) B[dir * 1024 + i] = (*bih)[i] + (*bhh)[i];
+            for (size_t i = 0; i < (size_t)1024 * 256; ++i) whh[(size_t)dir * 1024 * 256 + i] = (half_t)(*wh)[i];
+        }
+        if ((rc = build_linear(r, r->xs_gemm[layer], layer ? r->h0 : r->t7, W, B, 2048, 512, r->xs, 2048))) return rc;
+        if ((rc = upload(r->arena, whh.data(), whh.size() * sizeof(half_t), (void**)&r->whh[layer]))) return rc;
+        r->macs += r->xs_gemm[layer].macs_per_image + (int64_t)2 * T * 1024 * 256;
+    }
+    {
+        auto w = r->get("classifier.weight", (size_t)r->vocab * 512), b = r->get("classifier.bias", r->vocab);
+        if (!w || !b) return ERR_MISSING_KEY;
+        if (r->vocab > 128) return ERR_GEOMETRY;
+        if ((rc = build_linear(r, r->cls_gemm, r->h1, *w, *b, r->vocab, 512, r->logits_pad, 128))) return rc;
+        r->macs += r->cls_gemm.macs_per_image;
+    }
+    return 0;
+}
+
+}  // namespace vtd
+
+extern "C" {
+
+int vtd_recognizer_create(int vocab_size, int max_crops, vtd_recognizer** out) {
+    if (!out || vocab_size <= 0 || vocab_size > 128 || max_crops <= 0) return ERR_ARG;
+    auto* r = new vtd_recognizer();
+    r->vocab = vocab_size;
+    r->max_crops = max_crops;
+    *out = r;
+    return 0;
+}
+
+void vtd_recognizer_destroy(vtd_recognizer* r) { delete r; }
+
+int vtd_recognizer_set_tensor(vtd_recognizer* r, const char* key, const float* host_data, int64_t numel) {
+    if (!r || !key || !host_data || numel < 0) return ERR_ARG;
+    const std::string k = key;
+    if (k.rfind("cnn.", 0) != 0 && k.rfind("rnn.", 0) != 0 && k.rfind("classifier.", 0) != 0) return ERR_UNKNOWN_KEY;
+    if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return 0;
+    r->sd[k].assign(host_data, host_data + numel);
+    return 0;
+}
+
+int vtd_recognizer_finalize(vtd_recognizer* r, vtd_stream stream) {
+    if (!r || r->finalized) return ERR_ARG;
+    int rc = build_recognizer_graph(r);
+    if (rc) return rc;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return -(int)e;
+    r->sd.clear();
+    r->finalized = true;
+    return 0;
+}
+
+int vtd_recognizer_crop_resize(vtd_recognizer* r, const uint8_t* frames_dev, int n_frames, int height, int width,
+                               const int32_t* boxes_dev, int ncrops, vtd_stream stream) {
+    if (!r || !frames_dev || !boxes_dev || n_frames <= 0 || height <= 0 || width <= 0) return ERR_ARG;
+    if (!r->finalized) return ERR_NOT_FINALIZED;
+    if (ncrops <= 0 || ncrops > r->max_crops) return ERR_BATCH;
+    int rc = vtd_launch_crop_resize(frames_dev, height, width, boxes_dev, ncrops, r->resized, (hipStream_t)stream);
+    if (rc) return rc;
+    return vtd_launch_crnn_conv1(r->resized, nullptr, r->w1, r->b1, r->t1.ptr, ncrops, (hipStream_t)stream);
+}
+
+int vtd_recognizer_set_input_nchw(vtd_recognizer* r, const float* x_dev, int ncrops, vtd_stream stream) {
+    if (!r || !x_dev) return ERR_ARG;
+    if (!r->finalized) return ERR_NOT_FINALIZED;
+    if (ncrops <= 0 || ncrops > r->max_crops) return ERR_BATCH;
+    return vtd_launch_crnn_conv1(nullptr, x_dev, r->w1, r->b1, r->t1.ptr, ncrops, (hipStream_t)stream);
+}
+
+int vtd_recognizer_forward(vtd_recognizer* r, int ncrops, float* logits_dev, vtd_stream stream) {
+    if (!r || !logits_dev) return ERR_ARG;
+    if (!r->finalized) return ERR_NOT_FINALIZED;
+    if (ncrops <= 0 || ncrops > r->max_crops) return ERR_BATCH;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    for (const Op& o : r->ops) {
+        if (o.kind == Op::CONV) rc = launch_conv_op(o.conv, ncrops, s);
+        else rc = vtd_launch_maxpool(o.pin, o.pout, ncrops, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s);
+        if (rc) return rc;
+    }
+    half_t* hout[2] = {r->h0.ptr, r->h1.ptr};
+    for (int layer = 0; layer < 2; ++layer) {
+        if ((rc = launch_conv_op(r->xs_gemm[layer], ncrops, s))) return rc;
+        if ((rc = vtd_launch_lstm(r->xs, r->whh[layer], hout[layer], ncrops, 31, s))) return rc;
+    }
+    if ((rc = launch_conv_op(r->cls_gemm, ncrops, s))) return rc;
+    return vtd_launch_compact_rows(r->logits_pad, logits_dev, (int64_t)ncrops * 31, r->vocab, 128, s);
+}
+
+int vtd_recognizer_read_tap(vtd_recognizer* r, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream) {
+    if (!r || !name || !host_out) return ERR_ARG;
+    if (!r->finalized) return ERR_NOT_FINALIZED;
+    if (ncrops <= 0 || ncrops > r->max_crops) return ERR_BATCH;
+    if (std::string(name) == "resized") {  // uint8 [n,32,128,3] widened to float
+        if (capacity < (int64_t)ncrops * 32 * 128 * 3) return ERR_CAPACITY;
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return -(int)e;
+        std::vector<uint8_t> tmp((size_t)ncrops * 32 * 128 * 3);
+        e = hipMemcpy(tmp.data(), r->resized, tmp.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return -(int)e;
+        for (size_t i = 0; i < tmp.size(); ++i) host_out[i] = tmp[i];
+        return 0;
+    }
+    auto it = r->taps.find(name);
+    if (it == r->taps.end()) return ERR_UNKNOWN_KEY;
+    const TensorDesc& t = it->second;
+    if (capacity < (int64_t)ncrops * t.c * t.h * t.w) return ERR_CAPACITY;
+    return read_tensor_nchw(t, ncrops, t.c, host_out, (hipStream_t)stream);
+}
+
+int64_t vtd_recognizer_macs_per_crop(const vtd_recognizer* r) { return r ? r->macs : 0; }
+
+int vtd_ctc_greedy_decode(const float* logits_dev, int n, int T, int V, const int32_t* id2char_dev, int blank_id, int apply_softmax,
+                          int32_t* out_dev, vtd_stream stream) {
+    if (!logits_dev || !id2char_dev || !out_dev || n <= 0) return ERR_ARG;
+    return vtd_launch_ctc_greedy(logits_dev, n, T, V, V, id2char_dev, blank_id, apply_softmax, out_dev, (hipStream_t)stream);
+}
 
 }  // extern "C"

@@ -44,6 +44,16 @@ SIGNATURES = {
     "vtd_postproc_destroy": (None, [C.c_void_p]),
     "vtd_postproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "vtd_recognizer_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "vtd_recognizer_destroy": (None, [C.c_void_p]),
+    "vtd_recognizer_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "vtd_recognizer_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtd_recognizer_crop_resize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_recognizer_set_input_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_recognizer_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vtd_recognizer_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vtd_recognizer_macs_per_crop": (C.c_int64, [C.c_void_p]),
+    "vtd_ctc_greedy_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 

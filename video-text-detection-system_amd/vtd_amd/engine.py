@@ -196,3 +196,103 @@ def detector_profile(engine):
                                                    _stream_ptr()), "vtd_detector_get_profile")
         out.append((name.value.decode(), ms.value, calls.value, macs.value))
     return out
+
+
+class RecognizerEngine:
+    """CRNN on the GPU: crops (or reference-format [n,3,32,128] tensors) in, [n,31,V] logits / decoded text out."""
+
+    T = 31
+
+    def __init__(self, vocab_size, state_dict, max_crops=None):
+        self.lib = _native.require()
+        self.vocab_size = vocab_size
+        self.max_crops = max_crops or int(os.environ.get("VTD_MAX_CROPS", "512"))
+        self.lock = threading.Lock()
+        h = C.c_void_p()
+        _native.check(self.lib.vtd_recognizer_create(vocab_size, self.max_crops, C.byref(h)), "vtd_recognizer_create")
+        self.handle = h
+        try:
+            for key, value in state_dict.items():
+                if key.endswith("num_batches_tracked"):
+                    continue
+                arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
+                _native.check(self.lib.vtd_recognizer_set_tensor(h, key.encode(), arr.ctypes.data, arr.size),
+                              f"vtd_recognizer_set_tensor({key})")
+            _native.check(self.lib.vtd_recognizer_finalize(h, _stream_ptr()), "vtd_recognizer_finalize")
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vtd_recognizer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def macs_per_crop(self):
+        return int(self.lib.vtd_recognizer_macs_per_crop(self.handle))
+
+    def _forward_current(self, n):
+        logits = torch.empty((n, self.T, self.vocab_size), dtype=torch.float32, device="cuda")
+        _native.check(self.lib.vtd_recognizer_forward(self.handle, n, C.c_void_p(logits.data_ptr()), _stream_ptr()),
+                      "vtd_recognizer_forward")
+        return logits
+
+    def forward_logits(self, x):
+        """CRNN.forward on a reference-format tensor [n,3,32,128] (any device) -> [n,31,V] f32 cuda."""
+        if not torch.is_tensor(x) or x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 128):
+            raise ValueError("CRNN input must be [n,3,32,128] float")
+        outs = []
+        with self.lock:
+            for i in range(0, x.shape[0], self.max_crops):
+                xd = x[i:i + self.max_crops].to("cuda", torch.float32).contiguous()
+                _native.check(self.lib.vtd_recognizer_set_input_nchw(self.handle, C.c_void_p(xd.data_ptr()), xd.shape[0], _stream_ptr()),
+                              "vtd_recognizer_set_input_nchw")
+                outs.append(self._forward_current(xd.shape[0]))
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    def load_crops(self, frames, boxes):
+        """K6 + conv1 for boxes [(frame, x1, y1, x2, y2), ...] on a DeviceFrames batch; call with the lock held."""
+        b = boxes if torch.is_tensor(boxes) else torch.as_tensor(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
+        b = b.to("cuda", torch.int32).contiguous()
+        n = b.shape[0]
+        _native.check(self.lib.vtd_recognizer_crop_resize(self.handle, C.c_void_p(frames.tensor.data_ptr()), frames.n, frames.height,
+                                                          frames.width, C.c_void_p(b.data_ptr()), n, _stream_ptr()),
+                      "vtd_recognizer_crop_resize")
+        self._keep = (b, frames)
+        return n
+
+    def forward_crops(self, frames, boxes):
+        with self.lock:
+            n = self.load_crops(frames, boxes)
+            return self._forward_current(n)
+
+    def read_tap(self, name, n):
+        shape = (n, 32, 128, 3) if name == "resized" else (n, 512, 1, 31)
+        out = np.empty(shape, np.float32)
+        with self.lock:
+            _native.check(self.lib.vtd_recognizer_read_tap(self.handle, name.encode(), n, out.ctypes.data, out.size, _stream_ptr()),
+                          f"vtd_recognizer_read_tap({name})")
+        return out
+
+
+def ctc_greedy_decode(logits, id2char, blank_id=0, apply_softmax=True):
+    """[softmax +] the reference's greedy decode on the GPU.  logits: [n,T,V] float tensor (any device), logits when
+    apply_softmax else probabilities; id2char: list of code points / -1.  Returns [(text, confidence)]."""
+    lib = _native.require()
+    lg = logits.detach().to("cuda", torch.float32).contiguous()
+    n, T, V = lg.shape
+    table = torch.tensor(list(id2char)[:V] + [-1] * max(0, V - len(id2char)), dtype=torch.int32, device="cuda")
+    out = torch.empty((n, 2 + T), dtype=torch.int32, device="cuda")
+    _native.check(lib.vtd_ctc_greedy_decode(C.c_void_p(lg.data_ptr()), n, T, V, C.c_void_p(table.data_ptr()), blank_id,
+                                            1 if apply_softmax else 0, C.c_void_p(out.data_ptr()), _stream_ptr()),
+                  "vtd_ctc_greedy_decode")
+    host = out.cpu().numpy()
+    conf = host[:, 1].copy().view(np.float32)
+    return [("".join(chr(c) for c in host[i, 2:2 + host[i, 0]]), float(conf[i])) for i in range(n)]

@@ -194,7 +194,7 @@ class CRNN(nn.Module):
         if self._engine is None or self._engine_version != self._version:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = _e.RecognizerEngine(self.vocab_size, self.state_dict())
+            self._engine = _e.RecognizerEngine(self.vocab_size, self.state_dict(), getattr(self, "_max_crops", None))
             self._engine_version = self._version
         return self._engine
 
