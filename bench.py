@@ -72,8 +72,7 @@ def main():
     MAX_DET = 64
     pp = PostProcessor(B, 640, 640, max_out=MAX_DET)
     prob = torch.empty((B, 1, 640, 640), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world, B, MAX_DET, 16), dtype=torch.int32, device="cuda") if world > 1 else None
-    gathered_cnt = torch.empty((world, B), dtype=torch.int32, device="cuda") if world > 1 else None
+    from vtd_amd import shard
     import ctypes as C
     from vtd_amd import _native
     lib = eng.lib
@@ -84,8 +83,7 @@ def main():
         _native.check(lib.vtd_detector_forward(eng.handle, B, C.c_void_p(prob.data_ptr()), None, s))
         rec, cnt = pp.run_device(prob, [W] * B, [H] * B, 0.5)
         if world > 1:  # the one exchange step of the path: detections of every rank to every rank
-            dist.all_gather_into_tensor(gathered, rec.contiguous())
-            dist.all_gather_into_tensor(gathered_cnt, cnt.contiguous())
+            shard.gather_detections(rec, cnt)
         return rec, cnt
 
     def barrier():

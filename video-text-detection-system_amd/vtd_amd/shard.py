@@ -17,11 +17,13 @@ def gather_detections(records, counts, group=None):
     """records: [F, MAX_DET, 16] int32, counts: [F] int32 for this rank's F frames (same F on every rank, pad with
     count 0).  Returns ([W, F, MAX_DET, 16], [W, F]) on every rank."""
     world = dist.get_world_size(group)
-    rec_out = torch.empty((world,) + tuple(records.shape), dtype=records.dtype, device=records.device)
-    cnt_out = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
+    f = records.shape[0]
+    # concatenated-along-dim-0 output form: the one every backend (RCCL and gloo) accepts
+    rec_out = torch.empty((world * f,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+    cnt_out = torch.empty((world * f,), dtype=counts.dtype, device=counts.device)
     dist.all_gather_into_tensor(rec_out, records.contiguous(), group=group)
     dist.all_gather_into_tensor(cnt_out, counts.contiguous(), group=group)
-    return rec_out, cnt_out
+    return rec_out.view((world, f) + tuple(records.shape[1:])), cnt_out.view(world, f)
 
 
 def merge_by_frame(rec_all, cnt_all, n_frames):
