@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--backbone", default="resnet18")
-    ap.add_argument("--workload", default="detector", choices=["detector"])
+    ap.add_argument("--workload", default="full", choices=["full", "detector"],
+                    help="full = BASELINE configs[2] (detect + recognize); detector = configs[1]")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
     ap.add_argument("--layers-out", default=None, help="write the per-launch table as JSON to this path")
@@ -68,21 +69,40 @@ def main():
     frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
     dev_frames = DeviceFrames(frames)
     sd = weights.margin_detector_state_dict(args.backbone, 0)
-    eng = DetectorEngine(args.backbone, sd, max_batch=B)
-    MAX_DET = 64
-    pp = PostProcessor(B, 640, 640, max_out=MAX_DET)
-    prob = torch.empty((B, 1, 640, 640), dtype=torch.float32, device="cuda")
+    from vtd_amd import nets as mynets
     from vtd_amd import shard
+    from vtd_amd.pipeline import VideoTextPipeline
+    os.environ["VTD_MAX_BATCH"] = str(B)
+    pipe = VideoTextPipeline(use_transformer_ocr=False, backbone=args.backbone, batch_size=B)
+    pipe.detector.max_detections = MAX_DET = 64
+    pipe.detector.model.load_state_dict(sd)
+    rec_sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    pipe.recognizer.model.load_state_dict(rec_sd)
+    eng = pipe.detector.model.engine()
+    pp = pipe.detector._postprocessor(640, 640, B)
+    prob = torch.empty((B, 1, 640, 640), dtype=torch.float32, device="cuda")
     import ctypes as C
     from vtd_amd import _native
     lib = eng.lib
+    last = {}
 
-    def step():
+    def step_detector():
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         _native.check(lib.vtd_detector_preprocess(eng.handle, C.c_void_p(dev_frames.tensor.data_ptr()), B, H, W, s))
         _native.check(lib.vtd_detector_forward(eng.handle, B, C.c_void_p(prob.data_ptr()), None, s))
         rec, cnt = pp.run_device(prob, [W] * B, [H] * B, 0.5)
-        if world > 1:  # the one exchange step of the path: detections of every rank to every rank
+        last["n_det"] = cnt
+        return rec, cnt
+
+    def step_full():
+        results = pipe.process_device_batch(dev_frames)  # the product's batched pass, result dicts included
+        last["results"] = results
+        rec = pp.records[:B]
+        return rec, pp.counts[:B]
+
+    def step():
+        rec, cnt = step_full() if args.workload == "full" else step_detector()
+        if world > 1:  # the one exchange step of the path: detection records of every rank to every rank
             shard.gather_detections(rec, cnt)
         return rec, cnt
 
@@ -168,10 +188,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), 1xMI355X fp16"
-                       if args.workload == "detector" else "full", "global_batch": world * B, "frame": [H, W],
-                       "backbone": args.backbone, "parallelism": f"frames sharded over {world} rank(s)",
-                       "detections_last_step_rank0": n_det},
+            "config": {"workload": (f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), fp16"
+                                    if args.workload == "detector" else
+                                    f"B={B} {H}p frames, full pipeline: DBNet-{args.backbone} + crop + CRNN + CTC decode -> result dicts, fp16"),
+                       "global_batch": world * B, "frame": [H, W], "backbone": args.backbone,
+                       "parallelism": f"frames sharded over {world} rank(s), detections all-gathered",
+                       "detections_last_step_rank0": n_det,
+                       "crops_recognized_last_step_rank0": (sum(len(r["detections"]) for r in last["results"]) if "results" in last else 0)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

@@ -101,30 +101,35 @@ class VideoTextPipeline:
         return (shape is not None and len(shape) == 3 and shape[2] == 3
                 and all(getattr(f, "shape", None) == shape and getattr(f, "dtype", None) == np.uint8 for f in frames))
 
+    def process_device_batch(self, batch, frame_info=None) -> List[Dict]:
+        """The batched device pass on frames that are already resident in HBM (a ``DeviceFrames``): fused
+        preprocess -> DBNet -> post-process for every frame, then all crops of the batch through crop/resize ->
+        CRNN -> CTC decode.  Two small device->host reads (boxes, decoded text); everything else stays on the GPU."""
+        n = batch.n
+        frame_info = frame_info or [(i, 0.0) for i in range(n)]
+        detections = self.detector.detect_batch(batch, self.confidence_threshold)
+        boxes, owners = [], []
+        for i, dets in enumerate(detections):
+            for j, det in enumerate(dets):
+                x1, y1, x2, y2 = det["bbox"]
+                if x2 > x1 and y2 > y1:  # `cropped_text.size == 0` -> skipped (pipeliine.py:122-123)
+                    boxes.append((i, x1, y1, x2, y2))
+                    owners.append((i, j))
+        texts = self.recognizer.recognize_boxes(batch, boxes) if boxes else []
+        per_frame = [[] for _ in range(n)]
+        for (i, j), rec in zip(owners, texts):
+            det = detections[i][j]
+            per_frame[i].append({"bbox": det["bbox"], "text": rec["text"], "detection_confidence": det["confidence"],
+                                 "recognition_confidence": rec["confidence"], "polygon": det.get("polygon", [])})
+        return [{"frame_number": frame_info[i][0], "timestamp": frame_info[i][1], "detections": per_frame[i]} for i in range(n)]
+
     def _batched_device_pass(self, frames, frame_info) -> List[Dict]:
         from .engine import DeviceFrames
         results = []
         cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
         for start in range(0, len(frames), cap):
             chunk = frames[start:start + cap]
-            batch = DeviceFrames(chunk)
-            detections = self.detector.detect_batch(batch, self.confidence_threshold)
-            boxes, owners = [], []
-            for i, dets in enumerate(detections):
-                for j, det in enumerate(dets):
-                    x1, y1, x2, y2 = det["bbox"]
-                    if x2 > x1 and y2 > y1:  # `cropped_text.size == 0` -> skipped (pipeliine.py:122-123)
-                        boxes.append((i, x1, y1, x2, y2))
-                        owners.append((i, j))
-            texts = self.recognizer.recognize_boxes(batch, boxes) if boxes else []
-            per_frame = [[] for _ in chunk]
-            for (i, j), rec in zip(owners, texts):
-                det = detections[i][j]
-                per_frame[i].append({"bbox": det["bbox"], "text": rec["text"], "detection_confidence": det["confidence"],
-                                     "recognition_confidence": rec["confidence"], "polygon": det.get("polygon", [])})
-            for i in range(len(chunk)):
-                number, timestamp = frame_info[start + i]
-                results.append({"frame_number": number, "timestamp": timestamp, "detections": per_frame[i]})
+            results += self.process_device_batch(DeviceFrames(chunk), frame_info[start:start + cap])
         return results
 
     async def _process_frame_batch(self, frames: List[np.ndarray], frame_info: List[Tuple], output_dir: str) -> List[Dict]:
