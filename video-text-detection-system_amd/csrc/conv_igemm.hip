@@ -5,32 +5,46 @@
 //
 //   GEMM view      D[M x N] = A[M x K] * W^T,  M = n*ho*wo output pixels, N = Cout, K = kh*kw*Cin
 //   activations    ring-padded NHWC fp16 (TensorDesc): every tap of every output pixel is in bounds, so
-//                  the A tile is a pure gather of 16-byte chunks: address = pixel_base[m] + ktab[k/8]
-//   weights        [Cout][K] fp16, K contiguous in ktab order, BatchNorm folded on the host
-//   staging        global_load_lds_dwordx4 straight into LDS (no VGPR round trip), two LDS stages,
-//                  BK = 64 (128-byte rows); rows are XOR-swizzled on the SOURCE side
-//                  (chunk ^= (row>>1)&7) so every ds_read_b128 lane group hits 16 distinct 16-B slots
-//   math           v_mfma_f32_16x16x32_f16, weights as the A operand and pixels as the B operand so one
-//                  lane ends up with 4 consecutive channels of one pixel -> 8-byte packed stores
-//   epilogue       +bias, optional residual (optionally nearest-2x upsampled: FPN top-down add),
-//                  ReLU, fp16 NHWC store; or ConvTranspose(k2,s2) pixel shuffle; or fp32 row-major
-//   scheduling     one 256-thread workgroup per BM x BN tile; the linear block id is re-dealt so that
-//                  the 8 XCDs each own a contiguous run of tiles (neighbouring tiles share halo rows
-//                  and the weight panel in that XCD's L2)
+//                  the A tile is a pure gather of 16-byte chunks: pixel_base[m] + tap offset + chunk offset.
+//                  The tap walk (channel step, kernel column, kernel row) is wave-uniform scalar arithmetic, so the
+//                  only vector-memory traffic inside the main loop is the LDS-DMA itself
+//   weights        [Cout][K] fp16, K contiguous in tap-major order, BatchNorm folded on the host
+//   staging        global_load_lds_dwordx4 straight into LDS (no VGPR round trip), STAGES LDS buffers of
+//                  BK = 64 (128-byte rows); two K-steps stay in flight across the (raw) barrier behind a counted
+//                  s_waitcnt vmcnt; rows are XOR-swizzled on the SOURCE side (chunk ^= (row>>1)&7) so every
+//                  ds_read_b128 lane group hits 16 distinct 16-byte slots
+//   math           v_mfma_f32_16x16x32_f16; every wave owns a 64x64 sub-tile (4x4 fragments, 64 accumulators)
+//   epilogue       accumulators -> fp32 tile in LDS -> each thread finishes 8 consecutive channels of one pixel:
+//                  +bias, optional residual (optionally nearest-2x upsampled = FPN top-down add), ReLU,
+//                  one 16-byte store (full 128/256-byte lines per pixel); or ConvTranspose(k2,s2) pixel shuffle;
+//                  or fp32 row-major output
+//   scheduling     one workgroup per BM x BN tile; the linear block id is re-dealt so that the 8 XCDs each own a
+//                  contiguous run of tiles (neighbouring tiles share halo rows and the weight panel in that L2)
 #include "vtd_common.h"
 
 namespace {
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
-    static_assert(WM * WN == 4, "four waves per workgroup");
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int NT = NW * 64;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / 32;  // global_load_lds instructions per wave per K-step for the A tile
-    constexpr int B_INST = BN / 32;
+    constexpr int A_INST = BM / (8 * NW);  // global_load_lds instructions per wave per K-step for the A tile
+    constexpr int B_INST = BN / (8 * NW);
+    constexpr int LOADS = A_INST + B_INST;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
+    static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8), "tile/wave shape");
+    static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
+    constexpr int EPI_ROW = BN * 4 + 16;  // fp32 tile row stride (bytes), padded by one 16-byte slot
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -47,34 +61,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, con
     // ---- loader state: each lane owns one 16-byte chunk slot of A_INST + B_INST rows
     const int lrow = lane >> 3;
     const int c_log = (lane & 7) ^ (((w & 1) << 2) | (lane >> 4));  // logical K-chunk this lane fetches
+    const int c_off = (c_log >> 2) * p.k_hi_step + (c_log & 3) * 8; // its element offset inside a K-step
     const int howo = p.ho * p.wo;
     const half_t* aptr[A_INST];
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-        int m = m0 + (i * 4 + w) * 8 + lrow;
+        int m = m0 + (i * NW + w) * 8 + lrow;
         m = m < p.M ? m : p.M - 1;
         const int img = m / howo;
         const int rem = m - img * howo;
         const int oy = rem / p.wo, ox = rem - oy * p.wo;
-        aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c;
+        aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off;
     }
     const half_t* bptr[B_INST];
 #pragma unroll
-    for (int i = 0; i < B_INST; ++i) bptr[i] = p.wgt + (int64_t)(n0 + (i * 4 + w) * 8 + lrow) * p.K + c_log * 8;
-    const int* ktab = p.ktab + c_log;
+    for (int i = 0; i < B_INST; ++i) bptr[i] = p.wgt + (int64_t)(n0 + (i * NW + w) * 8 + lrow) * p.K + c_log * 8;
 
+    // K walk state (scalar): kb = element offset of the current K-step from the tap-(0,0) pixel
+    int kb = 0, t_c = 0, t_s = 0;
     auto stage = [&](int ks, int buf) {
-        const int koff = ktab[ks * 8];
         char* abase = smem + buf * STAGE;
         char* bbase = abase + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_INST; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(aptr[i] + koff),
-                                             (VTD_AS3 void*)(abase + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(aptr[i] + kb), (VTD_AS3 void*)(abase + (i * NW + w) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_INST; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64),
-                                             (VTD_AS3 void*)(bbase + (i * 4 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64), (VTD_AS3 void*)(bbase + (i * NW + w) * 1024), 16, 0, 0);
+        // advance to the next K-step (stages are always issued in K order)
+        kb += 64;
+        if (++t_c == p.cin_steps) {
+            t_c = 0;
+            kb += p.s_step - p.cin_steps * 64;
+            if (++t_s == p.kw) {
+                t_s = 0;
+                kb += p.r_step - p.kw * p.s_step;
+            }
+        }
     };
 
     // ---- compute state
@@ -92,13 +115,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, con
 
     const int nk = p.K >> 6;
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (STAGES == 3 && nk > 1) stage(1, 1);
 
+    int buf = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
-        const char* sb = smem + cur * STAGE;
+        // the loads of K-step ks have landed once at most the youngest prefetched step is still outstanding
+        if (STAGES == 3 && ks + 1 < nk) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // everyone's loads landed; everyone finished reading the buffer refilled below
+        {
+            const int ahead = ks + STAGES - 1;
+            if (ahead < nk) {
+                int nb = buf + STAGES - 1;
+                nb = nb >= STAGES ? nb - STAGES : nb;
+                stage(ahead, nb);
+            }
+        }
+        const char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
@@ -113,82 +146,176 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p, con
                 for (int j = 0; j < FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
 
-    // ---- epilogue: lane holds channels ch..ch+3 (ch = .. + (lane>>4)*4) of pixel (lane&15) per fragment
-    const int chq = (lane >> 4) * 4;
+    // ---- epilogue phase 1: accumulators -> fp32 tile in LDS (weights were the A operand: a lane holds 4
+    //      consecutive channels (lane>>4)*4.. of pixel lane&15), plus the pixel coordinates of the tile rows
+    __syncthreads();  // all waves are done with the staging buffers
+    int* pix = (int*)(smem + BM * EPI_ROW);  // [BM][2]: image (or -1 past M), oy | ox << 16
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int img = -1, oy = 0, ox = 0;
+        if (m < p.M) {
+            img = m / howo;
+            const int rem = m - img * howo;
+            oy = rem / p.wo;
+            ox = rem - oy * p.wo;
+        }
+        pix[2 * tid] = img;
+        pix[2 * tid + 1] = oy | (ox << 16);
+    }
+    {
+        const int chq = (lane >> 4) * 4;
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * TM + j * 16 + frow;
-        if (m >= p.M) continue;
-        const int img = m / howo;
-        const int rem = m - img * howo;
-        const int oy = rem / p.wo, ox = rem - oy * p.wo;
+        for (int j = 0; j < FM; ++j)
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int ch = n0 + wn * TN + i * 16 + chq;
-            if (ch >= p.cout) continue;
-            const float4 bv = *(const float4*)(p.bias + ch);
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-            if (p.flags & EPI_RESIDUAL) {
-                const int64_t ro = ((int64_t)(img * p.res_hp + (oy >> p.res_shift) + p.res_ring) * p.res_wp +
+            for (int i = 0; i < FN; ++i)
+                *(floatx4*)(smem + (wm * TM + j * 16 + frow) * EPI_ROW + (wn * TN + i * 16 + chq) * 4) = acc[i][j];
+    }
+    __syncthreads();
+
+    // ---- epilogue phase 2: one thread = 8 consecutive channels of one pixel
+    constexpr int CPR = BN / 8;  // 16-byte output chunks per tile row
+    static_assert(NT % CPR == 0, "a thread keeps its channel chunk across iterations");
+    const int cc = tid % CPR;
+    const int ch = n0 + cc * 8;
+    if (ch < p.cout) {
+        float bias[8];
+        {
+            const float4 b0 = *(const float4*)(p.bias + ch), b1 = *(const float4*)(p.bias + ch + 4);
+            bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+        }
+        int oc = ch, dy = 0, dx = 0;
+        if (p.flags & EPI_PIXEL_SHUFFLE) {
+            const int blk = ch / p.ps_cout;
+            oc = ch - blk * p.ps_cout;
+            dy = blk >> 1;
+            dx = blk & 1;
+        }
+        constexpr int ROWS_PER_IT = NT / CPR;
+        constexpr int ITERS = BM / ROWS_PER_IT;
+        // issue every residual read of this thread up front: one round trip instead of one per row
+        half8 resv[ITERS];
+        if (p.flags & EPI_RESIDUAL) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int row = tid / CPR + it * ROWS_PER_IT;
+                const int img = pix[2 * row];
+                const int yx = pix[2 * row + 1];
+                const int oy = yx & 0xffff, ox = yx >> 16;
+                const int64_t ro = ((int64_t)((img < 0 ? 0 : img) * p.res_hp + (oy >> p.res_shift) + p.res_ring) * p.res_wp +
                                     (ox >> p.res_shift) + p.res_ring) * p.cout + ch;
-                const half4 rv = *(const half4*)(p.res + ro);
+                resv[it] = *(const half8*)(p.res + ro);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        for (int it = 0; it < ITERS; ++it) {
+            const int row = tid / CPR + it * ROWS_PER_IT;
+            const int img = pix[2 * row];
+            if (img < 0) continue;
+            const int yx = pix[2 * row + 1];
+            const int oy = yx & 0xffff, ox = yx >> 16;
+            const floatx4 v0 = *(const floatx4*)(smem + row * EPI_ROW + cc * 32);
+            const floatx4 v1 = *(const floatx4*)(smem + row * EPI_ROW + cc * 32 + 16);
+            float v[8] = {v0[0] + bias[0], v0[1] + bias[1], v0[2] + bias[2], v0[3] + bias[3],
+                          v1[0] + bias[4], v1[1] + bias[5], v1[2] + bias[6], v1[3] + bias[7]};
+            if (p.flags & EPI_RESIDUAL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)resv[it][e];
             }
             if (p.flags & EPI_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
             if (p.flags & EPI_OUT_F32) {
-                float* o = (float*)p.out + (int64_t)m * p.ldc + ch;
-                if (ch + 3 < p.cout) {
+                float* o = (float*)p.out + (int64_t)(m0 + row) * p.ldc + ch;
+                if (ch + 7 < p.cout) {
                     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
-                    for (int e = 0; e < 4 && ch + e < p.cout; ++e) o[e] = v[e];
+                    for (int e = 0; e < 8 && ch + e < p.cout; ++e) o[e] = v[e];
                 }
             } else {
-                int py = oy, px = ox, oc = ch;
-                if (p.flags & EPI_PIXEL_SHUFFLE) {
-                    const int blk = ch / p.ps_cout;
-                    oc = ch - blk * p.ps_cout;
-                    py = 2 * oy + (blk >> 1);
-                    px = 2 * ox + (blk & 1);
-                }
+                const int py = (p.flags & EPI_PIXEL_SHUFFLE) ? 2 * oy + dy : oy;
+                const int px = (p.flags & EPI_PIXEL_SHUFFLE) ? 2 * ox + dx : ox;
                 const int64_t oo = ((int64_t)(img * p.out_hp + py + p.out_ring) * p.out_wp + px + p.out_ring) * p.out_c + oc;
-                half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *(half4*)((half_t*)p.out + oo) = hv;
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                *(half8*)((half_t*)p.out + oo) = hv;
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = p.cout_pad / BN;
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int stage_bytes = STAGES * (BM + BN) * 128;
+    constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8;
+    constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN>,
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, STAGES>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, p, tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, stream, p, tiles_n);
     return -(int)hipGetLastError();
 }
 
 }  // namespace
 
+// ---- tile configurations.  Which one wins depends on the layer (M, N, K, how memory-bound it is), so the network
+// graphs time the valid candidates once per batch size (vtd_api.cpp: autotune) instead of guessing.
+//   id  tile      waves stages  LDS      blocks/CU
+//   0   256x128   8     3       144 KB   1      K-heavy, N >= 128: least L2->LDS traffic per FLOP
+//   1   128x128   4     2        68 KB   2
+//   2   128x128   4     3        96 KB   1
+//   3   256x64    4     2        80 KB   2
+//   4   256x64    4     3       120 KB   1
+//   5   128x64    4     2        48 KB   3      short-K / store-bound layers: more blocks in flight per CU
+//   6   128x64    4     3        72 KB   2
+int vtd_conv_num_configs() { return 7; }
+
+bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
+    switch (cfg) {
+        case 0: case 1: case 2: return p.cout_pad % 128 == 0;
+        case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
+        default: return false;
+    }
+}
+
+int vtd_conv_default_config(const ConvParams& p) {
+    if (p.cout_pad % 128 == 0) {
+        const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * (p.cout_pad / 128);
+        return (big_tiles >= 512 && p.K >= 512) ? 0 : 1;
+    }
+    return p.K >= 1024 ? 3 : 5;
+}
+
 // Host entry used by the network graphs in vtd_api.cpp.  Shapes are validated here: a mismatch must
 // never reach the kernel (an out-of-bounds gather can take the whole node down).
-int vtd_launch_conv(const ConvParams& p, hipStream_t stream) {
+int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
     if (p.M <= 0 || p.K <= 0 || (p.K & 63) || p.cout <= 0 || (p.cout_pad & 63) || p.cout > p.cout_pad) return -1001;
-    if ((p.cout & 3) && !(p.flags & EPI_OUT_F32)) return -1002;
+    if ((p.cout & 7) && !(p.flags & EPI_OUT_F32)) return -1002;
     if ((p.flags & EPI_OUT_F32) && (p.ldc & 3)) return -1003;
-    if (p.cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2>(p, stream);
-    return launch_cfg<256, 64, 4, 1>(p, stream);
+    if ((p.flags & EPI_PIXEL_SHUFFLE) && (p.ps_cout & 7)) return -1004;
+    if (p.ho >= 65536 || p.wo >= 32768) return -1005;
+    if (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw))) return -1006;
+    if (cfg < 0) cfg = vtd_conv_default_config(p);
+    if (!vtd_conv_config_valid(p, cfg)) return -1007;
+    switch (cfg) {
+        case 0: return launch_cfg<256, 128, 4, 2, 3>(p, stream);
+        case 1: return launch_cfg<128, 128, 2, 2, 2>(p, stream);
+        case 2: return launch_cfg<128, 128, 2, 2, 3>(p, stream);
+        case 3: return launch_cfg<256, 64, 4, 1, 2>(p, stream);
+        case 4: return launch_cfg<256, 64, 4, 1, 3>(p, stream);
+        case 5: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
+        default: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
+    }
 }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -14,7 +15,9 @@
 #include "vtd_common.h"
 
 // kernel launchers (defined in the .hip files)
-int vtd_launch_conv(const ConvParams& p, hipStream_t stream);
+int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream);
+int vtd_conv_num_configs();
+bool vtd_conv_config_valid(const ConvParams& p, int cfg);
 int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
                           const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream);
 int vtd_launch_nchw_to_input(const float* x, half_t* out, int n, hipStream_t stream);
@@ -80,7 +83,7 @@ struct ConvOp {
     bool has_res = false;
     half_t* w = nullptr;
     float* bias = nullptr;
-    int* ktab = nullptr;
+    int k_hi_step = 32, cin_steps = 1, kw = 1, s_step = 0, r_step = 0;  // scalar K walk (ConvParams)
     int K = 0, cout = 0, cout_pad = 0, stride = 1, in_y0 = 0, in_x0 = 0, flags = 0, ps_cout = 0, res_shift = 0;
     int ho = 0, wo = 0;           // GEMM row decomposition (input-pixel grid for transposed conv)
     int64_t macs_per_image = 0;
@@ -98,10 +101,9 @@ struct Op {
     int final_slot = 0;  // 0 = probability, 1 = threshold
 };
 
-static int launch_conv_op(const ConvOp& c, int n, hipStream_t s) {
-    ConvParams p;
+static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     std::memset(&p, 0, sizeof(p));
-    p.in = c.in.ptr; p.wgt = c.w; p.ktab = c.ktab; p.bias = c.bias;
+    p.in = c.in.ptr; p.wgt = c.w; p.k_hi_step = c.k_hi_step; p.cin_steps = c.cin_steps; p.kw = c.kw; p.s_step = c.s_step; p.r_step = c.r_step; p.bias = c.bias;
     p.res = c.has_res ? c.res.ptr : nullptr;
     p.out = (c.flags & EPI_OUT_F32) ? c.out_f32 : (void*)c.out.ptr;
     p.M = n * c.ho * c.wo; p.K = c.K; p.cout = c.cout; p.cout_pad = c.cout_pad;
@@ -110,7 +112,44 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s) {
     p.out_hp = c.out.hp; p.out_wp = c.out.wp; p.out_c = c.out.c; p.out_ring = c.out.ring;
     p.res_hp = c.res.hp; p.res_wp = c.res.wp; p.res_ring = c.res.ring; p.res_shift = c.res_shift;
     p.ps_cout = c.ps_cout; p.flags = c.flags; p.ldc = c.ldc;
-    return vtd_launch_conv(p, s);
+}
+
+static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1) {
+    ConvParams p;
+    fill_conv_params(c, n, p);
+    return vtd_launch_conv(p, cfg, s);
+}
+
+// Times every valid tile configuration of one convolution at batch n and returns the fastest (HIP events on `s`).
+// The launch writes the op's real output buffer; the graph recomputes it on the next forward anyway.
+static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
+    ConvParams p;
+    fill_conv_params(c, n, p);
+    hipEvent_t e0, e1;
+    VTD_HIP_CHECK(hipEventCreate(&e0));
+    VTD_HIP_CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    int best_id = -1, rc = 0;
+    for (int cfg = 0; cfg < vtd_conv_num_configs() && !rc; ++cfg) {
+        if (!vtd_conv_config_valid(p, cfg)) continue;
+        if ((rc = vtd_launch_conv(p, cfg, s))) break;  // warm-up (also sets the LDS attribute)
+        (void)hipEventRecord(e0, s);
+        for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_conv(p, cfg, s);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = ERR_ARG; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; best_id = cfg; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *best_cfg = best_id;
+    return rc;
+}
+
+static bool autotune_enabled() {
+    const char* e = std::getenv("VTD_AUTOTUNE");
+    return !(e && e[0] == '0');
 }
 
 // ---- Pillow resample coefficient tables (8-bit path, bilinear filter with antialias support scaling)
@@ -190,6 +229,7 @@ struct vtd_detector : vtd::ModelBase {
     std::map<std::pair<int, int>, PreTables> pre;
     int64_t macs = 0;
     float* final_out[2] = {nullptr, nullptr};
+    std::map<int, std::vector<int>> tuned;  // batch size -> tile config per op (-1 = heuristic)
     // optional per-op HIP-event timing (bench / roofline accounting)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -226,6 +266,7 @@ struct vtd_recognizer : vtd::ModelBase {
     float* logits_pad = nullptr;  // [D*31, 128]
     std::map<std::string, TensorDesc> taps;
     int64_t macs = 0;
+    std::map<int, std::vector<int>> tuned;  // crop count bucket -> config per conv launch (ops..., xs0, xs1, cls)
 };
 
 namespace vtd {
@@ -284,15 +325,11 @@ static int build_conv(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc
                         (half_t)(float)((double)(*w)[(((size_t)co * cin + c) * kh + r) * kw + s] * f.scale[co]);
     std::vector<float> bias(cout_pad, 0.f);
     for (int co = 0; co < cout; ++co) bias[co] = (float)f.shift[co];
-    std::vector<int> ktab(K / 8);
-    for (int q = 0; q < K / 8; ++q) {
-        const int k = q * 8, tap = k / cin, c0 = k % cin, r = tap / kw, s = tap % kw;
-        ktab[q] = (r * in.wp + s) * in.c + c0;
-    }
+    // cin % 64 == 0: a K-step never straddles two taps
+    op.cin_steps = cin / 64; op.kw = kw; op.s_step = in.c; op.r_step = in.wp * in.c; op.k_hi_step = 32;
     int rc;
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
-    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
     op.in = in; op.out = out; op.K = K; op.cout = cout; op.cout_pad = cout_pad; op.stride = stride;
     op.in_y0 = in.ring - pad; op.in_x0 = in.ring - pad; op.flags = flags; op.ho = ho; op.wo = wo;
     op.macs_per_image = (int64_t)ho * wo * cout * K;
@@ -317,15 +354,11 @@ static int build_stem(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc
                     wp[(size_t)co * K + r * 32 + s * 4 + c] = (half_t)(float)((double)(*w)[(((size_t)co * 3 + c) * 7 + r) * 7 + s] * f.scale[co]);
     std::vector<float> bias(64);
     for (int co = 0; co < 64; ++co) bias[co] = (float)f.shift[co];
-    std::vector<int> ktab(K / 8);
-    for (int q = 0; q < K / 8; ++q) {
-        const int k = q * 8, r = k / 32, within = k % 32;
-        ktab[q] = r * in.wp * 4 + within;
-    }
+    // one K-step = two kernel rows of 32 elements (8 taps x 4 ch): chunks 4-7 sit one input row below chunks 0-3
+    op.cin_steps = 1; op.kw = 1; op.s_step = 0; op.r_step = 2 * in.wp * 4; op.k_hi_step = in.wp * 4;
     int rc;
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
-    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
     op.in = in; op.out = out; op.K = K; op.cout = 64; op.cout_pad = 64; op.stride = 2;
     op.in_y0 = 0; op.in_x0 = 0; op.flags = EPI_RELU; op.ho = out.h; op.wo = out.w;
     op.macs_per_image = (int64_t)out.h * out.w * 64 * 147;
@@ -349,12 +382,10 @@ static int build_convt(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDes
             for (int ci = 0; ci < cin; ++ci)
                 wp[(size_t)nrow * K + ci] = (half_t)(float)((double)(*w)[((size_t)ci * cout + co) * 4 + blk] * f.scale[co]);
         }
-    std::vector<int> ktab(K / 8);
-    for (int q = 0; q < K / 8; ++q) ktab[q] = q * 8;
+    op.cin_steps = K / 64; op.kw = 1; op.s_step = 0; op.r_step = 0; op.k_hi_step = 32;
     int rc;
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
-    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
     op.in = in; op.out = out; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
     op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = flags | EPI_PIXEL_SHUFFLE; op.ps_cout = cout;
     op.ho = in.h; op.wo = in.w;
@@ -564,12 +595,10 @@ static int build_linear(ModelBase* d, ConvOp& op, const TensorDesc& in, const st
     for (size_t i = 0; i < (size_t)N * K; ++i) wp[i] = (half_t)W[i];
     std::vector<float> b(cout_pad, 0.f);
     for (int i = 0; i < N; ++i) b[i] = bias[i];
-    std::vector<int> ktab(K / 8);
-    for (int q = 0; q < K / 8; ++q) ktab[q] = q * 8;
+    op.cin_steps = K / 64; op.kw = 1; op.s_step = 0; op.r_step = 0; op.k_hi_step = 32;
     int rc;
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, b.data(), b.size() * sizeof(float), (void**)&op.bias))) return rc;
-    if ((rc = upload(d->arena, ktab.data(), ktab.size() * sizeof(int), (void**)&op.ktab))) return rc;
     op.in = in; op.out = in; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
     op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = EPI_OUT_F32; op.ho = in.h; op.wo = in.w;
     op.out_f32 = out_f32; op.ldc = ldc;
@@ -699,6 +728,18 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
     if (n <= 0 || n > d->max_batch) return ERR_BATCH;
     hipStream_t s = (hipStream_t)stream;
     float* outs[2] = {prob_dev, thresh_dev};
+    auto tit = d->tuned.find(n);
+    if (tit == d->tuned.end()) {
+        std::vector<int> cfgs(d->ops.size(), -1);
+        if (autotune_enabled())
+            for (size_t oi = 0; oi < d->ops.size(); ++oi)
+                if (d->ops[oi].kind == Op::CONV) {
+                    int rc = autotune_conv(d->ops[oi].conv, n, s, &cfgs[oi]);
+                    if (rc) return rc;
+                }
+        tit = d->tuned.emplace(n, std::move(cfgs)).first;
+    }
+    const std::vector<int>& cfgs = tit->second;
     for (size_t oi = 0; oi < d->ops.size(); ++oi) {
         const Op& o = d->ops[oi];
         int rc = 0;
@@ -711,7 +752,7 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
             VTD_HIP_CHECK(hipEventRecord(e0, s));
         }
         switch (o.kind) {
-            case Op::CONV: rc = launch_conv_op(o.conv, n, s); break;
+            case Op::CONV: rc = launch_conv_op(o.conv, n, s, cfgs[oi]); break;
             case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
             case Op::FINAL: rc = vtd_launch_final_convt_sigmoid(o.pin, o.fw, o.fbias, outs[o.final_slot], n, s); break;
         }
@@ -758,8 +799,10 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     const Op& o = d->ops[op_index];
     if (o.kind == Op::CONV) {
         const ConvOp& c = o.conv;
-        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d", c.cout_pad % 128 == 0 ? "128,128" : "256,64",
-                      c.ho * c.wo, c.cout, c.K);
+        static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3"};
+        int cfg = -1;
+        if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
+        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d", cfg >= 0 ? kTile[cfg] : "default", c.ho * c.wo, c.cout, c.K);
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
     } else {
@@ -946,17 +989,36 @@ int vtd_recognizer_forward(vtd_recognizer* r, int ncrops, float* logits_dev, vtd
     if (ncrops <= 0 || ncrops > r->max_crops) return ERR_BATCH;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    for (const Op& o : r->ops) {
-        if (o.kind == Op::CONV) rc = launch_conv_op(o.conv, ncrops, s);
+    // tile configs are tuned per power-of-two bucket of the crop count (the count changes from batch to batch)
+    int bucket = 1;
+    while (bucket < ncrops) bucket <<= 1;
+    bucket = std::min(bucket, r->max_crops);
+    auto tit = r->tuned.find(bucket);
+    const size_t nops = r->ops.size();
+    if (tit == r->tuned.end()) {
+        std::vector<int> cfgs(nops + 3, -1);
+        if (autotune_enabled()) {
+            for (size_t oi = 0; oi < nops; ++oi)
+                if (r->ops[oi].kind == Op::CONV && (rc = autotune_conv(r->ops[oi].conv, bucket, s, &cfgs[oi]))) return rc;
+            for (int layer = 0; layer < 2; ++layer)
+                if ((rc = autotune_conv(r->xs_gemm[layer], bucket, s, &cfgs[nops + layer]))) return rc;
+            if ((rc = autotune_conv(r->cls_gemm, bucket, s, &cfgs[nops + 2]))) return rc;
+        }
+        tit = r->tuned.emplace(bucket, std::move(cfgs)).first;
+    }
+    const std::vector<int>& cfgs = tit->second;
+    for (size_t oi = 0; oi < nops; ++oi) {
+        const Op& o = r->ops[oi];
+        if (o.kind == Op::CONV) rc = launch_conv_op(o.conv, ncrops, s, cfgs[oi]);
         else rc = vtd_launch_maxpool(o.pin, o.pout, ncrops, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s);
         if (rc) return rc;
     }
     half_t* hout[2] = {r->h0.ptr, r->h1.ptr};
     for (int layer = 0; layer < 2; ++layer) {
-        if ((rc = launch_conv_op(r->xs_gemm[layer], ncrops, s))) return rc;
+        if ((rc = launch_conv_op(r->xs_gemm[layer], ncrops, s, cfgs[nops + layer]))) return rc;
         if ((rc = vtd_launch_lstm(r->xs, r->whh[layer], hout[layer], ncrops, 31, s))) return rc;
     }
-    if ((rc = launch_conv_op(r->cls_gemm, ncrops, s))) return rc;
+    if ((rc = launch_conv_op(r->cls_gemm, ncrops, s, cfgs[nops + 2]))) return rc;
     return vtd_launch_compact_rows(r->logits_pad, logits_dev, (int64_t)ncrops * 31, r->vocab, 128, s);
 }
 

@@ -36,8 +36,11 @@ enum : int {
 
 struct ConvParams {
     const half_t* in;      // input tensor base (ring-padded NHWC)
-    const half_t* wgt;     // packed weights [Cout_pad][K] fp16, K contiguous, K order given by ktab
-    const int* ktab;       // per 16-byte K-chunk: element offset from the tap-(0,0) pixel of the output position
+    const half_t* wgt;     // packed weights [Cout_pad][K] fp16, K contiguous, K in tap-major order
+    // K walk, all wave-uniform so it runs on the scalar unit: a tap is `cin_steps` K-steps of 64 channels; after a
+    // tap the gather moves `s_step` elements (next kernel column), after `kw` taps `r_step` (next kernel row)
+    int cin_steps, kw, s_step, r_step;
+    int k_hi_step;         // element offset between chunks 0-3 and 4-7 of a K-step (32 = contiguous; stem: one input row)
     const float* bias;     // [Cout_pad] fp32 (conv bias and BatchNorm folded)
     const half_t* res;     // optional residual tensor (ring-padded NHWC, C = cout)
     void* out;             // output tensor base
