@@ -94,11 +94,30 @@ def main():
         last["n_det"] = cnt
         return rec, cnt
 
+    # full workload: the product's batched pass, software-pipelined three deep exactly as a video loop would run it --
+    # detector(i) is enqueued, then the host collects the boxes of batch i-1 and enqueues its recogniser, then builds
+    # the result dicts of batch i-2.  Every step retires one whole batch (result dicts included).
+    inflight = {"det": None, "rec": None}
+
     def step_full():
-        results = pipe.process_device_batch(dev_frames)  # the product's batched pass, result dicts included
-        last["results"] = results
-        rec = pp.records[:B]
-        return rec, pp.counts[:B]
+        job = pipe.submit_detection(dev_frames)
+        keep = job["det"]["keep"]
+        if inflight["rec"] is not None:
+            last["results"] = pipe.collect(inflight["rec"])
+            inflight["rec"] = None
+        if inflight["det"] is not None:
+            inflight["rec"] = pipe.submit_recognition(inflight["det"])
+        inflight["det"] = job
+        return keep[1][:B], keep[2][:B]
+
+    def drain_full():
+        while inflight["det"] is not None or inflight["rec"] is not None:
+            if inflight["rec"] is not None:
+                last["results"] = pipe.collect(inflight["rec"])
+                inflight["rec"] = None
+            if inflight["det"] is not None:
+                inflight["rec"] = pipe.submit_recognition(inflight["det"])
+                inflight["det"] = None
 
     def step():
         rec, cnt = step_full() if args.workload == "full" else step_detector()
@@ -113,12 +132,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.workload == "full":
+        drain_full()
     barrier()
     if not args.no_profile:
         lib.vtd_detector_set_profiling(eng.handle, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec, cnt = step()
+    if args.workload == "full":
+        drain_full()  # K batches submitted -> K batches retired inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

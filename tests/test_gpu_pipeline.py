@@ -80,3 +80,17 @@ def test_mock_seams_switch_off_the_fast_path(pipeline):
         out = asyncio.run(p._process_frame_batch(frames, [(0, 0.0), (1, 0.1)], "/tmp"))
         assert det.call_count == 2 and rec.call_count == 2
         assert out[0]["detections"][0]["text"] == "TEST TEXT" and out[0]["detections"][0]["polygon"] == []
+
+
+def test_pipelined_halves_equal_the_one_shot_pass(pipeline):
+    """submit_detection / submit_recognition / collect with two batches in flight == process_device_batch."""
+    from vtd_amd.engine import DeviceFrames
+    p, _, _ = pipeline
+    a = DeviceFrames([synth.text_frame(100 + i)[0] for i in range(3)])
+    b = DeviceFrames([synth.text_frame(200 + i)[0] for i in range(3)])
+    exp_a, exp_b = p.process_device_batch(a), p.process_device_batch(b)
+    ja = p.submit_detection(a)
+    jb = p.submit_detection(b)          # second detector pass enqueued before the first is collected
+    ja = p.submit_recognition(ja)
+    jb = p.submit_recognition(jb)
+    assert p.collect(ja) == exp_a and p.collect(jb) == exp_b

@@ -152,18 +152,33 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams p) {
+    // W_hh of one direction is 512 KB -- exactly one CU's whole register file -- so it cannot be fully resident
+    // next to the state.  Split per wave (32 fragments of 1 KB: 4 gates x 8 K-chunks):
+    //   K-chunks 0-3 -> registers (64 VGPRs), 4-5 -> LDS (8 KB per wave, lane-linear), 6-7 -> re-streamed from L2
+    // each step (128 KB per workgroup instead of 512 KB), issued first so the other 24 MFMAs cover their latency.
     constexpr int HROW = 264;  // 256 + 8 halves of padding: rows land on different LDS banks
-    __shared__ __attribute__((aligned(16))) half_t hbuf[2][16][HROW];
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    half_t (*hbuf)[16][HROW] = (half_t (*)[16][HROW])lsm;          // [2][16][HROW]
+    char* wlds = lsm + 2 * 16 * HROW * sizeof(half_t);              // [16 waves][8 frags][64 lanes][16 B]
     const int dir = blockIdx.y;
     const int crop0 = blockIdx.x * 16;
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;          // hidden units [16wv, 16wv+16)
     const int fr = lane & 15, fq = lane >> 4;
 
-    // W_hh fragments (A operand): row = unit (lane&15), k = 32*kc + 8*(lane>>4) .. +8.  The whole W_hh of one
-    // direction is 512 KB -- exactly one CU's register file -- so it cannot stay resident next to the state;
-    // each step re-streams it from L2 (all workgroups of a direction read the same 512 KB, so it stays L2-hot).
+    // fragment (gate g, chunk kc): A operand, row = unit (lane&15), k = 32*kc + 8*(lane>>4) .. +8
     const half_t* wlane = p.whh + (int64_t)dir * 1024 * 256 + (int64_t)(wv * 16 + fr) * 256 + fq * 8;
+    half8 wreg[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) wreg[g][kc] = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
+    char* wl = wlds + (wv * 8) * 1024 + lane * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kc = 4; kc < 6; ++kc)
+            *(half8*)(wl + (g * 2 + (kc - 4)) * 1024) = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
 
     for (int i = threadIdx.x; i < 2 * 16 * HROW; i += 1024) (&hbuf[0][0][0])[i] = (half_t)0.f;
     float cst[4] = {0.f, 0.f, 0.f, 0.f};  // cell state of units 16wv + 4fq + j, crop crop0 + fr
@@ -174,6 +189,12 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
+        // streamed fragments first (their addresses do not depend on h)
+        half8 ws[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 6; kc < 8; ++kc) ws[g][kc - 6] = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
         floatx4 acc[4];
         const float* xrow = p.xs + ((int64_t)crop * p.T + t) * 2048 + dir * 1024 + wv * 16 + fq * 4;
 #pragma unroll
@@ -182,13 +203,25 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
             acc[g] = floatx4{v.x, v.y, v.z, v.w};
         }
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
+        for (int kc = 0; kc < 4; ++kc) {
+            const half8 hf = *(const half8*)(&hbuf[cur][fr][kc * 32 + fq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[g][kc], hf, acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kc = 4; kc < 6; ++kc) {
             const half8 hf = *(const half8*)(&hbuf[cur][fr][kc * 32 + fq * 8]);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const half8 wf = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
+                const half8 wf = *(const half8*)(wl + (g * 2 + (kc - 4)) * 1024);
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, hf, acc[g], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int kc = 6; kc < 8; ++kc) {
+            const half8 hf = *(const half8*)(&hbuf[cur][fr][kc * 32 + fq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[g][kc - 6], hf, acc[g], 0, 0, 0);
         }
         half4 hv;
 #pragma unroll
@@ -288,7 +321,13 @@ int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float
 
 int vtd_launch_lstm(const float* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s) {
     LstmParams p{xs, whh, hout, D, T};
-    hipLaunchKernelGGL(lstm_recurrence_kernel, dim3((D + 15) / 16, 2), dim3(1024), 0, s, p);
+    constexpr int lds = 2 * 16 * 264 * 2 + 16 * 8 * 1024;  // h double buffer + LDS-resident W_hh slice
+    static bool attr_done = false;
+    if (!attr_done) {
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_recurrence_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lstm_recurrence_kernel, dim3((D + 15) / 16, 2), dim3(1024), lds, s, p);
     return -(int)hipGetLastError();
 }
 

@@ -107,6 +107,33 @@ class TextDetector:
             logger.error(f"Detection failed: {e}")
             return []
 
+    # ---- asynchronous batched path (software pipelining across batches) ------------------------------------------
+    def submit_batch(self, batch: DeviceFrames, confidence_threshold: float = 0.5):
+        """Enqueue preprocess -> DBNet -> post-process for a resident batch plus an asynchronous copy of the detection
+        records to pinned host memory; nothing synchronises.  ``finish_batch(ticket)`` returns the per-frame dicts."""
+        n = batch.n
+        prob = self.model(batch)["probability"]
+        pp = self._postprocessor(prob.shape[-2], prob.shape[-1], n)
+        with pp.lock:
+            records = torch.empty((n, pp.max_out, 16), dtype=torch.int32, device="cuda")
+            counts = torch.empty((n,), dtype=torch.int32, device="cuda")
+            pp.run_device(prob.reshape(n, prob.shape[-2], prob.shape[-1]), [batch.width] * n, [batch.height] * n,
+                          confidence_threshold, records, counts)
+            host_rec = torch.empty((n, pp.max_out, 16), dtype=torch.int32).pin_memory()
+            host_cnt = torch.empty((n,), dtype=torch.int32).pin_memory()
+            host_rec.copy_(records, non_blocking=True)
+            host_cnt.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return {"rec": host_rec, "cnt": host_cnt, "event": ev, "max_out": pp.max_out, "keep": (prob, records, counts, batch)}
+
+    @staticmethod
+    def finish_batch(ticket):
+        from .engine import records_to_dicts
+        ticket["event"].synchronize()
+        rec, cnt = ticket["rec"].numpy(), ticket["cnt"].numpy()
+        return [records_to_dicts(rec[i, :min(int(cnt[i]), ticket["max_out"])]) for i in range(len(cnt))]
+
     def detect_batch(self, frames, confidence_threshold: float = 0.5):
         """Batched fast path: ``frames`` is a list/array of equally sized BGR frames or a ``DeviceFrames``.
         One fused preprocess + DBNet + post-process launch sequence; never raises (returns [] per frame)."""

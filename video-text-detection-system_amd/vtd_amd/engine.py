@@ -147,19 +147,22 @@ class PostProcessor:
         except Exception:
             pass
 
-    def run_device(self, prob, orig_w, orig_h, threshold):
-        """Enqueue only; returns (records[n,max_out,16] int32 view, counts[n]) device tensors."""
+    def run_device(self, prob, orig_w, orig_h, threshold, records=None, counts=None):
+        """Enqueue only; returns (records[n,max_out,16] int32 view, counts[n]) device tensors.  Pass `records` /
+        `counts` to keep several batches in flight (the default buffers are overwritten by the next call)."""
         n = prob.shape[0]
+        records = self.records if records is None else records
+        counts = self.counts if counts is None else counts
         if prob.dtype != torch.float32 or not prob.is_cuda or tuple(prob.shape[-2:]) != (self.h, self.w):
             raise ValueError("probability maps must be float32 cuda tensors of the workspace's map size")
         prob = prob.reshape(n, self.h, self.w).contiguous()
         ow = np.ascontiguousarray(orig_w, dtype=np.int32)
         oh = np.ascontiguousarray(orig_h, dtype=np.int32)
         _native.check(self.lib.vtd_postproc_run(self.handle, C.c_void_p(prob.data_ptr()), n, ow.ctypes.data, oh.ctypes.data,
-                                                float(threshold), C.c_void_p(self.records.data_ptr()),
-                                                C.c_void_p(self.counts.data_ptr()), _stream_ptr()), "vtd_postproc_run")
+                                                float(threshold), C.c_void_p(records.data_ptr()),
+                                                C.c_void_p(counts.data_ptr()), _stream_ptr()), "vtd_postproc_run")
         self._keep = (prob, ow, oh)
-        return self.records[:n], self.counts[:n]
+        return records[:n], counts[:n]
 
     def run(self, prob, orig_w, orig_h, threshold, debug=False):
         with self.lock:
@@ -172,17 +175,18 @@ class PostProcessor:
 
 def records_to_dicts(rec, debug=False):
     """vtd_detection records -> the reference's detection dicts (text_detector.py:172-176): plain Python ints/floats."""
-    out = []
-    conf = rec[:, 12].copy().view(np.float32) if len(rec) else []
-    area = rec[:, 13].copy().view(np.float32) if len(rec) else []
-    for j in range(len(rec)):
-        r = rec[j]
-        d = {"bbox": [int(v) for v in r[0:4]], "confidence": float(conf[j]),
-             "polygon": [[int(r[4 + 2 * q]), int(r[5 + 2 * q])] for q in range(4)]}
-        if debug:
-            d["_area"] = float(area[j])
-            d["_first"] = (int(r[14]), int(r[15]))
-        out.append(d)
+    if len(rec) == 0:
+        return []
+    bbox = rec[:, 0:4].tolist()
+    poly = rec[:, 4:12].reshape(-1, 4, 2).tolist()
+    conf = np.ascontiguousarray(rec[:, 12]).view(np.float32).tolist()
+    out = [{"bbox": b, "confidence": c, "polygon": p} for b, c, p in zip(bbox, conf, poly)]
+    if debug:
+        area = np.ascontiguousarray(rec[:, 13]).view(np.float32).tolist()
+        first = rec[:, 14:16].tolist()
+        for d, a, f in zip(out, area, first):
+            d["_area"] = a
+            d["_first"] = tuple(f)
     return out
 
 
@@ -273,6 +277,30 @@ class RecognizerEngine:
             n = self.load_crops(frames, boxes)
             return self._forward_current(n)
 
+    def submit_decode(self, frames, boxes_np, id2char_dev, blank_id=0):
+        """Enqueue crop/resize -> CRNN -> softmax+CTC decode for boxes_np ([k,5] int32) and an asynchronous copy of the
+        decoded records to pinned host memory.  Returns a ticket for ``finish_decode`` (nothing synchronises here)."""
+        k = int(boxes_np.shape[0])
+        host_boxes = torch.from_numpy(np.ascontiguousarray(boxes_np, dtype=np.int32)).pin_memory()
+        with self.lock:
+            dev_boxes = host_boxes.to("cuda", non_blocking=True)
+            n = self.load_crops(frames, dev_boxes)
+            logits = self._forward_current(n)
+            out = torch.empty((k, 2 + self.T), dtype=torch.int32, device="cuda")
+            _native.check(self.lib.vtd_ctc_greedy_decode(C.c_void_p(logits.data_ptr()), k, self.T, self.vocab_size,
+                                                         C.c_void_p(id2char_dev.data_ptr()), blank_id, 1, C.c_void_p(out.data_ptr()),
+                                                         _stream_ptr()), "vtd_ctc_greedy_decode")
+            host = torch.empty((k, 2 + self.T), dtype=torch.int32).pin_memory()
+            host.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return {"host": host, "event": ev, "keep": (host_boxes, dev_boxes, logits, out, frames)}
+
+    @staticmethod
+    def finish_decode(ticket):
+        ticket["event"].synchronize()
+        return decode_records_to_text(ticket["host"].numpy())
+
     def read_tap(self, name, n):
         shape = (n, 32, 128, 3) if name == "resized" else (n, 512, 1, 31)
         out = np.empty(shape, np.float32)
@@ -293,6 +321,12 @@ def ctc_greedy_decode(logits, id2char, blank_id=0, apply_softmax=True):
     _native.check(lib.vtd_ctc_greedy_decode(C.c_void_p(lg.data_ptr()), n, T, V, C.c_void_p(table.data_ptr()), blank_id,
                                             1 if apply_softmax else 0, C.c_void_p(out.data_ptr()), _stream_ptr()),
                   "vtd_ctc_greedy_decode")
-    host = out.cpu().numpy()
-    conf = host[:, 1].copy().view(np.float32)
-    return [("".join(chr(c) for c in host[i, 2:2 + host[i, 0]]), float(conf[i])) for i in range(n)]
+    return decode_records_to_text(out.cpu().numpy())
+
+
+def decode_records_to_text(host):
+    """[n][2+T] int32 decode records -> [(text, confidence)]."""
+    conf = np.ascontiguousarray(host[:, 1]).view(np.float32).tolist()
+    lens = host[:, 0].tolist()
+    rows = host[:, 2:].tolist()
+    return [("".join(map(chr, rows[i][:lens[i]])), conf[i]) for i in range(len(lens))]

@@ -123,6 +123,34 @@ class VideoTextPipeline:
                                  "recognition_confidence": rec["confidence"], "polygon": det.get("polygon", [])})
         return [{"frame_number": frame_info[i][0], "timestamp": frame_info[i][1], "detections": per_frame[i]} for i in range(n)]
 
+    # ---- the same pass split into enqueue / collect halves so consecutive batches overlap: while the host reads the
+    # boxes of batch i and launches its recogniser, the GPU already runs the detector of batch i+1
+    def submit_detection(self, batch):
+        return {"batch": batch, "det": self.detector.submit_batch(batch, self.confidence_threshold)}
+
+    def submit_recognition(self, job):
+        detections = self.detector.finish_batch(job["det"])
+        boxes, owners = [], []
+        for i, dets in enumerate(detections):
+            for j, det in enumerate(dets):
+                x1, y1, x2, y2 = det["bbox"]
+                if x2 > x1 and y2 > y1:
+                    boxes.append((i, x1, y1, x2, y2))
+                    owners.append((i, j))
+        job.update(detections=detections, owners=owners, rec=self.recognizer.submit_boxes(job["batch"], boxes))
+        return job
+
+    def collect(self, job, frame_info=None) -> List[Dict]:
+        n = job["batch"].n
+        frame_info = frame_info or [(i, 0.0) for i in range(n)]
+        texts = self.recognizer.finish_boxes(job["rec"])
+        per_frame = [[] for _ in range(n)]
+        for (i, j), rec in zip(job["owners"], texts):
+            det = job["detections"][i][j]
+            per_frame[i].append({"bbox": det["bbox"], "text": rec["text"], "detection_confidence": det["confidence"],
+                                 "recognition_confidence": rec["confidence"], "polygon": det.get("polygon", [])})
+        return [{"frame_number": frame_info[i][0], "timestamp": frame_info[i][1], "detections": per_frame[i]} for i in range(n)]
+
     def _batched_device_pass(self, frames, frame_info) -> List[Dict]:
         from .engine import DeviceFrames
         results = []

@@ -101,6 +101,25 @@ class TextRecognizer:
             logger.error(f"CRNN batch recognition failed: {e}")
             return [{"text": "", "confidence": 0.0}] * len(images)
 
+    # asynchronous variant for the pipelined batch loop
+    def submit_boxes(self, frames: DeviceFrames, boxes):
+        if len(boxes) == 0:
+            return None
+        eng = self.model.engine()
+        if getattr(self, "_id2char_dev", None) is None:
+            self._id2char_dev = torch.tensor(self._id2char, dtype=torch.int32, device="cuda")
+        arr = np.asarray(boxes, dtype=np.int32).reshape(-1, 5)
+        return [eng.submit_decode(frames, arr[i:i + eng.max_crops], self._id2char_dev) for i in range(0, len(arr), eng.max_crops)]
+
+    def finish_boxes(self, tickets):
+        if not tickets:
+            return []
+        eng = self.model.engine()
+        out = []
+        for t in tickets:
+            out += [{"text": text, "confidence": conf} for text, conf in eng.finish_decode(t)]
+        return out
+
     # batched fast path used by VideoTextPipeline: crops taken on the device out of resident frames
     def recognize_boxes(self, frames: DeviceFrames, boxes):
         if len(boxes) == 0:
