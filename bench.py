@@ -63,7 +63,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
+        # backend "nccl" is RCCL on ROCm; VTD_DIST_BACKEND=gloo lets two ranks rehearse the N>1 path on one GPU
+        dist.init_process_group(os.environ.get("VTD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     B, H, W = args.batch, args.height, args.width
     frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
@@ -99,15 +100,24 @@ def main():
     # the result dicts of batch i-2.  Every step retires one whole batch (result dicts included).
     inflight = {"det": None, "rec": None}
 
+    host_t = {"submit_det": 0.0, "collect": 0.0, "submit_rec": 0.0}
+
     def step_full():
+        t_a = time.perf_counter()
         job = pipe.submit_detection(dev_frames)
         keep = job["det"]["keep"]
+        t_b = time.perf_counter()
         if inflight["rec"] is not None:
             last["results"] = pipe.collect(inflight["rec"])
             inflight["rec"] = None
+        t_c = time.perf_counter()
         if inflight["det"] is not None:
             inflight["rec"] = pipe.submit_recognition(inflight["det"])
         inflight["det"] = job
+        t_d = time.perf_counter()
+        host_t["submit_det"] += t_b - t_a
+        host_t["collect"] += t_c - t_b
+        host_t["submit_rec"] += t_d - t_c
         return keep[1][:B], keep[2][:B]
 
     def drain_full():
@@ -149,6 +159,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.workload == "full" and rank == 0:
+        print("host seconds inside step calls (includes waiting on events):", {k: round(v, 4) for k, v in host_t.items()},
+              "elapsed", round(elapsed, 4), file=sys.stderr)
     # ---- sanity: the timed path produced detections (not part of the timed region)
     counts = cnt.cpu().numpy()
     n_det = int(counts.sum())

@@ -175,6 +175,54 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
     __syncthreads();
 
+    if constexpr (BN == 256) {
+        // ---- fused DB-head tail (EPI_HEAD_FINAL): one thread = one (input pixel, 2x2 block) = 64 channels of the
+        // ConvT1 output -> BN/ReLU -> ConvT(64->1) -> sigmoid -> a 2x2 patch of the probability map.
+        // A quad of lanes shares one (pixel, block): lane q of the quad owns channels 16q..16q+15, keeps the matching
+        // 4x16 slice of the final weights in registers and the quad combines its partial sums with two shuffles.
+        float* hb = (float*)(smem + BM * EPI_ROW + BM * 8);  // [256] bias of this GEMM (BN folded)
+        for (int i = tid; i < 256; i += NT) hb[i] = p.bias[i];
+        const int qd = tid & 3;
+        float w6[4][16];
+#pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) w6[o4][c] = p.head_w[o4 * 64 + qd * 16 + c];
+        __syncthreads();
+        for (int item = tid >> 2; item < BM * 4; item += NT / 4) {
+            const int row = item >> 2, blk = item & 3;
+            const int img = pix[2 * row];
+            const int yx = pix[2 * row + 1];
+            const int oy = yx & 0xffff, ox = yx >> 16;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const char* src = smem + row * EPI_ROW + blk * 256 + qd * 64;
+            const float* bsrc = hb + blk * 64 + qd * 16;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const floatx4 v = *(const floatx4*)(src + c4 * 16);
+                const floatx4 bv = *(const floatx4*)(bsrc + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = v[e] + bv[e];
+                    a = a > 0.f ? a : 0.f;
+#pragma unroll
+                    for (int o4 = 0; o4 < 4; ++o4) o[o4] += a * w6[o4][c4 * 4 + e];
+                }
+            }
+#pragma unroll
+            for (int o4 = 0; o4 < 4; ++o4) {
+                o[o4] += __shfl_xor(o[o4], 1);
+                o[o4] += __shfl_xor(o[o4], 2);
+            }
+            if (img < 0 || qd != 0) continue;
+            const int W4 = 4 * p.wo;
+            float* dst = p.prob_out + ((int64_t)img * 4 * p.ho + 4 * oy + 2 * (blk >> 1)) * W4 + 4 * ox + 2 * (blk & 1);
+            *(float2*)dst = make_float2(1.f / (1.f + expf(-(o[0] + p.head_b))), 1.f / (1.f + expf(-(o[1] + p.head_b))));
+            *(float2*)(dst + W4) = make_float2(1.f / (1.f + expf(-(o[2] + p.head_b))), 1.f / (1.f + expf(-(o[3] + p.head_b))));
+        }
+        return;
+    }
+
     // ---- epilogue phase 2: one thread = 8 consecutive channels of one pixel
     constexpr int CPR = BN / 8;  // 16-byte output chunks per tile row
     static_assert(NT % CPR == 0, "a thread keeps its channel chunk across iterations");
@@ -255,7 +303,7 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = p.cout_pad / BN;
     constexpr int stage_bytes = STAGES * (BM + BN) * 128;
-    constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8;
+    constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -280,9 +328,11 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //   4   256x64    4     3       120 KB   1
 //   5   128x64    4     2        48 KB   3      short-K / store-bound layers: more blocks in flight per CU
 //   6   128x64    4     3        72 KB   2
-int vtd_conv_num_configs() { return 7; }
+//   7   64x256    4     2        80 KB   2      only for the fused DB-head tail (EPI_HEAD_FINAL needs all 256 columns)
+int vtd_conv_num_configs() { return 8; }
 
 bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
+    if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
     switch (cfg) {
         case 0: case 1: case 2: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
@@ -291,6 +341,7 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
 }
 
 int vtd_conv_default_config(const ConvParams& p) {
+    if (p.flags & EPI_HEAD_FINAL) return 7;
     if (p.cout_pad % 128 == 0) {
         const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * (p.cout_pad / 128);
         return (big_tiles >= 512 && p.K >= 512) ? 0 : 1;
@@ -306,6 +357,7 @@ int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
     if ((p.flags & EPI_OUT_F32) && (p.ldc & 3)) return -1003;
     if ((p.flags & EPI_PIXEL_SHUFFLE) && (p.ps_cout & 7)) return -1004;
     if (p.ho >= 65536 || p.wo >= 32768) return -1005;
+    if ((p.flags & EPI_HEAD_FINAL) && (p.cout != 256 || p.cout_pad != 256 || !p.head_w || !p.prob_out)) return -1008;
     if (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw))) return -1006;
     if (cfg < 0) cfg = vtd_conv_default_config(p);
     if (!vtd_conv_config_valid(p, cfg)) return -1007;
@@ -316,6 +368,7 @@ int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
         case 3: return launch_cfg<256, 64, 4, 1, 2>(p, stream);
         case 4: return launch_cfg<256, 64, 4, 1, 3>(p, stream);
         case 5: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
-        default: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
+        case 6: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
+        default: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
     }
 }

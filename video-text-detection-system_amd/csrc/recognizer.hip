@@ -195,12 +195,14 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int kc = 6; kc < 8; ++kc) ws[g][kc - 6] = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
+        // input projection x_t W_ih^T + b: loaded now, added after the MFMAs so its HBM latency hides behind them
         floatx4 acc[4];
+        float4 xin[4];
         const float* xrow = p.xs + ((int64_t)crop * p.T + t) * 2048 + dir * 1024 + wv * 16 + fq * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 v = *(const float4*)(xrow + g * 256);
-            acc[g] = floatx4{v.x, v.y, v.z, v.w};
+            xin[g] = *(const float4*)(xrow + g * 256);
+            acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
@@ -226,7 +228,12 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
         half4 hv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float ig = sigmoidf_(acc[0][j]), fg = sigmoidf_(acc[1][j]), gg = tanhf_(acc[2][j]), og = sigmoidf_(acc[3][j]);
+            const float xi[4] = {j == 0 ? xin[0].x : j == 1 ? xin[0].y : j == 2 ? xin[0].z : xin[0].w,
+                                 j == 0 ? xin[1].x : j == 1 ? xin[1].y : j == 2 ? xin[1].z : xin[1].w,
+                                 j == 0 ? xin[2].x : j == 1 ? xin[2].y : j == 2 ? xin[2].z : xin[2].w,
+                                 j == 0 ? xin[3].x : j == 1 ? xin[3].y : j == 2 ? xin[3].z : xin[3].w};
+            const float ig = sigmoidf_(acc[0][j] + xi[0]), fg = sigmoidf_(acc[1][j] + xi[1]), gg = tanhf_(acc[2][j] + xi[2]),
+                        og = sigmoidf_(acc[3][j] + xi[3]);
             cst[j] = fg * cst[j] + ig * gg;
             hv[j] = (half_t)(og * tanhf_(cst[j]));
         }

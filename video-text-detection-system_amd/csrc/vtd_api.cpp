@@ -89,6 +89,8 @@ struct ConvOp {
     int64_t macs_per_image = 0;
     void* out_f32 = nullptr;      // EPI_OUT_F32 destination
     int ldc = 0;
+    const float* head_w = nullptr;  // EPI_HEAD_FINAL
+    float head_b = 0.f;
 };
 
 struct Op {
@@ -112,11 +114,13 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     p.out_hp = c.out.hp; p.out_wp = c.out.wp; p.out_c = c.out.c; p.out_ring = c.out.ring;
     p.res_hp = c.res.hp; p.res_wp = c.res.wp; p.res_ring = c.res.ring; p.res_shift = c.res_shift;
     p.ps_cout = c.ps_cout; p.flags = c.flags; p.ldc = c.ldc;
+    p.head_w = c.head_w; p.head_b = c.head_b; p.prob_out = (float*)c.out_f32;
 }
 
-static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1) {
+static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, float* prob_out = nullptr) {
     ConvParams p;
     fill_conv_params(c, n, p);
+    if (prob_out) p.prob_out = prob_out;
     return vtd_launch_conv(p, cfg, s);
 }
 
@@ -536,15 +540,16 @@ static int build_detector_graph(vtd_detector* d) {
     const char* branch[2] = {"head.probability_head.", "head.threshold_head."};
     for (int br = 0; br < 2; ++br) {
         const std::string hp = branch[br];
-        TensorDesc h1, h2;
+        TensorDesc h1;
         if ((rc = new_tensor(160, 160, 64, h1))) return rc;
-        if ((rc = new_tensor(320, 320, 64, h2))) return rc;
         Fold f1, f2;
         if ((rc = fold_bn(d, hp + "1", hp + "0.bias", 64, f1))) return rc;
         ConvOp c1;
         if ((rc = build_conv(d, c1, p2, h1, hp + "0.weight", f1, 256, 64, 3, 3, 1, 1, EPI_RELU))) return rc;
         if ((rc = fold_bn(d, hp + "4", hp + "3.bias", 64, f2))) return rc;
+        // ConvT(64->64)+BN+ReLU and ConvT(64->1)+sigmoid in one launch: the 64x320x320 intermediate never touches HBM
         ConvOp c2;
+        TensorDesc h2 = make_desc(B, 320, 320, 64, 1, 1);  // shape bookkeeping only (no allocation)
         if ((rc = build_convt(d, c2, h1, h2, hp + "3.weight", f2, 64, 64, EPI_RELU))) return rc;
         auto w6 = d->get(hp + "6.weight", 64 * 4), b6 = d->get(hp + "6.bias", 1);
         if (!w6 || !b6) return ERR_MISSING_KEY;
@@ -553,17 +558,17 @@ static int build_detector_graph(vtd_detector* d) {
             for (int ci = 0; ci < 64; ++ci) wf[blk * 64 + ci] = (*w6)[ci * 4 + blk];
         float* wdev = nullptr;
         if ((rc = upload(d->arena, wf.data(), wf.size() * sizeof(float), (void**)&wdev))) return rc;
-        Op o1, o2, o3;
+        c2.flags = EPI_HEAD_FINAL;
+        c2.head_w = wdev;
+        c2.head_b = (*b6)[0];
+        Op o1, o2;
         o1.kind = Op::CONV; o1.conv = c1; o1.final_slot = br;
-        o2.kind = Op::CONV; o2.conv = c2; o2.final_slot = br;
-        o3.kind = Op::FINAL; o3.pin = h2; o3.fw = wdev; o3.fbias = (*b6)[0]; o3.final_slot = br;
+        o2.kind = Op::FINAL; o2.conv = c2; o2.final_slot = br;
         d->ops.push_back(o1);
         d->ops.push_back(o2);
-        d->ops.push_back(o3);
         if (br == 0) {
             d->macs += c1.macs_per_image + c2.macs_per_image + (int64_t)320 * 320 * 4 * 64;
             d->taps["head1"] = h1;
-            d->taps["head2"] = h2;
         }
     }
     return 0;
@@ -754,13 +759,13 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
         switch (o.kind) {
             case Op::CONV: rc = launch_conv_op(o.conv, n, s, cfgs[oi]); break;
             case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
-            case Op::FINAL: rc = vtd_launch_final_convt_sigmoid(o.pin, o.fw, o.fbias, outs[o.final_slot], n, s); break;
+            case Op::FINAL: rc = launch_conv_op(o.conv, n, s, 7, outs[o.final_slot]); break;
         }
         if (rc) return rc;
         if (d->profiling) {
             VTD_HIP_CHECK(hipEventRecord(e1, s));
             d->ev_spans.push_back({(int)oi, {e0, e1}});
-            d->prof_macs[oi] += (o.kind == Op::CONV) ? (double)o.conv.macs_per_image * n : 0.0;
+            d->prof_macs[oi] += (o.kind != Op::POOL) ? (double)o.conv.macs_per_image * n : 0.0;
         }
     }
     return 0;
@@ -806,7 +811,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
     } else {
-        std::snprintf(name, name_cap, "final_convt_sigmoid");
+        std::snprintf(name, name_cap, "conv_igemm<64,256,s2> ConvT1+ConvT2+sigmoid fused M/img=%d", o.conv.ho * o.conv.wo);
     }
     *total_ms = d->prof_ms[op_index];
     *calls = d->prof_calls[op_index];

@@ -32,6 +32,8 @@ enum : int {
     EPI_RESIDUAL = 2,      // += res[n, oy>>res_shift, ox>>res_shift, ch]   (res_shift=1: fused nearest-2x upsample)
     EPI_PIXEL_SHUFFLE = 4, // ConvTranspose2d(k=2,s=2) as GEMM: channel block q=(ky*2+kx) -> pixel (2oy+ky, 2ox+kx)
     EPI_OUT_F32 = 8,       // plain [M, ldc] float32 row-major output (LSTM gate pre-activations, logits)
+    EPI_HEAD_FINAL = 16,   // DB head tail fused: this GEMM is ConvT(64->64,k2,s2)+BN+ReLU; the epilogue applies
+                           // ConvT(64->1,k2,s2)+sigmoid and writes the 4x4 fp32 probabilities of each input pixel
 };
 
 struct ConvParams {
@@ -57,6 +59,9 @@ struct ConvParams {
     int ps_cout;           // pixel-shuffle: channels per (ky,kx) block
     int flags;
     int ldc;               // EPI_OUT_F32 row stride
+    const float* head_w;   // EPI_HEAD_FINAL: [4][64] final ConvT weights (ky2*2+kx2 major), head_b its bias
+    float head_b;
+    float* prob_out;       // EPI_HEAD_FINAL: [n, 4*ho, 4*wo] float32
 };
 
 #define VTD_HIP_CHECK(expr)                                   \

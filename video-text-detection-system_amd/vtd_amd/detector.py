@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .engine import DeviceFrames, PostProcessor
+from .engine import PINNED, DeviceFrames, PostProcessor
 from .nets import DBNet
 
 logger = logging.getLogger(__name__)
@@ -119,8 +119,8 @@ class TextDetector:
             counts = torch.empty((n,), dtype=torch.int32, device="cuda")
             pp.run_device(prob.reshape(n, prob.shape[-2], prob.shape[-1]), [batch.width] * n, [batch.height] * n,
                           confidence_threshold, records, counts)
-            host_rec = torch.empty((n, pp.max_out, 16), dtype=torch.int32).pin_memory()
-            host_cnt = torch.empty((n,), dtype=torch.int32).pin_memory()
+            host_rec = PINNED.take((n, pp.max_out, 16))
+            host_cnt = PINNED.take((n,))
             host_rec.copy_(records, non_blocking=True)
             host_cnt.copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
@@ -132,7 +132,10 @@ class TextDetector:
         from .engine import records_to_dicts
         ticket["event"].synchronize()
         rec, cnt = ticket["rec"].numpy(), ticket["cnt"].numpy()
-        return [records_to_dicts(rec[i, :min(int(cnt[i]), ticket["max_out"])]) for i in range(len(cnt))]
+        out = [records_to_dicts(rec[i, :min(int(cnt[i]), ticket["max_out"])]) for i in range(len(cnt))]
+        PINNED.release(ticket["rec"])
+        PINNED.release(ticket["cnt"])
+        return out
 
     def detect_batch(self, frames, confidence_threshold: float = 0.5):
         """Batched fast path: ``frames`` is a list/array of equally sized BGR frames or a ``DeviceFrames``.

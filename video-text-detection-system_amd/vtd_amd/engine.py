@@ -18,6 +18,30 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class PinnedPool:
+    """Recycles pinned host staging buffers (hipHostMalloc costs far more than the copies they serve).  A buffer is
+    handed out again only after `release`, which callers do once the event guarding its last copy has completed."""
+
+    def __init__(self):
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def take(self, shape, dtype=torch.int32):
+        key = (tuple(shape), dtype)
+        with self._lock:
+            lst = self._free.get(key)
+            if lst:
+                return lst.pop()
+        return torch.empty(shape, dtype=dtype).pin_memory()
+
+    def release(self, t):
+        with self._lock:
+            self._free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
+PINNED = PinnedPool()
+
+
 class DeviceFrames:
     """A batch of equally sized uint8 BGR HWC frames resident in HBM ([n,H,W,3] cuda tensor)."""
 
@@ -281,7 +305,8 @@ class RecognizerEngine:
         """Enqueue crop/resize -> CRNN -> softmax+CTC decode for boxes_np ([k,5] int32) and an asynchronous copy of the
         decoded records to pinned host memory.  Returns a ticket for ``finish_decode`` (nothing synchronises here)."""
         k = int(boxes_np.shape[0])
-        host_boxes = torch.from_numpy(np.ascontiguousarray(boxes_np, dtype=np.int32)).pin_memory()
+        host_boxes = PINNED.take((k, 5))
+        host_boxes.numpy()[...] = boxes_np
         with self.lock:
             dev_boxes = host_boxes.to("cuda", non_blocking=True)
             n = self.load_crops(frames, dev_boxes)
@@ -290,7 +315,7 @@ class RecognizerEngine:
             _native.check(self.lib.vtd_ctc_greedy_decode(C.c_void_p(logits.data_ptr()), k, self.T, self.vocab_size,
                                                          C.c_void_p(id2char_dev.data_ptr()), blank_id, 1, C.c_void_p(out.data_ptr()),
                                                          _stream_ptr()), "vtd_ctc_greedy_decode")
-            host = torch.empty((k, 2 + self.T), dtype=torch.int32).pin_memory()
+            host = PINNED.take((k, 2 + self.T))
             host.copy_(out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -299,7 +324,10 @@ class RecognizerEngine:
     @staticmethod
     def finish_decode(ticket):
         ticket["event"].synchronize()
-        return decode_records_to_text(ticket["host"].numpy())
+        out = decode_records_to_text(ticket["host"].numpy())
+        PINNED.release(ticket["host"])
+        PINNED.release(ticket["keep"][0])
+        return out
 
     def read_tap(self, name, n):
         shape = (n, 32, 128, 3) if name == "resized" else (n, 512, 1, 31)
