@@ -57,6 +57,10 @@ void vtd_detector_destroy(vtd_detector* d);
  * e.g. "backbone.0.weight", "fpn.inner_blocks.2.bias", "head.probability_head.3.weight"; float32,
  * PyTorch memory order.  Unknown keys are rejected, "num_batches_tracked" keys are accepted and ignored. */
 int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_data, int64_t numel);
+/* Build options, before finalize.  "fuse_fpn_head" (default 1): evaluate FPN lateral(C2) + top-down add + P2 smooth +
+ * head conv as one algebraically composed convolution (the 256-channel P2 map is never formed; its "p2" tap is then
+ * unavailable).  0 keeps the layer-by-layer graph. */
+int vtd_detector_set_option(vtd_detector* d, const char* name, int value);
 /* Folds BatchNorm, repacks to the kernels' fp16 layouts and uploads.  Fails (-1103) if a key is missing. */
 int vtd_detector_finalize(vtd_detector* d, vtd_stream stream);
 /* K1 = cvtColor(BGR2RGB) + ToPILImage + Resize((640,640)) + ToTensor + Normalize (text_detector.py:99-104,

@@ -21,7 +21,16 @@ def _rel(a, b):
 def r18(hip):
     from vtd_amd.engine import DetectorEngine
     sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
-    eng = DetectorEngine("resnet18", sd, max_batch=4)
+    eng = DetectorEngine("resnet18", sd, max_batch=4, options={"fuse_fpn_head": 0})  # layer-by-layer graph: every tap exists
+    yield eng, sd
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def r18_fused(hip):
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    eng = DetectorEngine("resnet18", sd, max_batch=4)  # default: FPN top + head entry algebraically composed
     yield eng, sd
     eng.close()
 
@@ -64,6 +73,34 @@ def test_dbnet_r18_taps_and_probability(r18):
     assert dp <= 2e-3
     band = float((np.abs(ref["probability"].numpy() - 0.5) < 2e-3).mean())
     print("may-flip band fraction at thr=0.5:", band)
+
+
+def test_dbnet_fused_fpn_head_entry(r18, r18_fused):
+    """The composed (5x5 on C2 + 3x3 on L3, 16 weight classes, 25 bias classes) head entry must reproduce the
+    layer-by-layer graph everywhere, borders included: compare the post-ReLU head1 tap and the probabilities against
+    the fp32 oracle and against the unfused engine."""
+    eng_u, sd = r18
+    eng_f, _ = r18_fused
+    x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(12))
+    ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
+    h1_ref = torch.relu(onets._bn(torch.nn.functional.conv2d(ref["p2"], sd["head.probability_head.0.weight"],
+                                                             sd["head.probability_head.0.bias"], 1, 1), sd, "head.probability_head.1")).numpy()
+    pf = eng_f.forward(x, want_threshold=True)
+    h1_f = eng_f.read_tap("head1", 2)
+    pu = eng_u.forward(x)["probability"].cpu().numpy()
+    h1_u = eng_u.read_tap("head1", 2)
+    e_f, e_u = _rel(h1_f, h1_ref), _rel(h1_u, h1_ref)
+    border = np.zeros((160, 160), bool)
+    border[[0, 1, 158, 159], :] = True
+    border[:, [0, 1, 158, 159]] = True
+    e_border = float(np.abs(h1_f - h1_ref)[:, :, border].max() / np.abs(h1_ref).max())
+    print("head1 rel err fused", e_f, "unfused", e_u, "fused border", e_border)
+    assert e_f < 1.5e-2 and e_border < 1.5e-2
+    dp = float(np.abs(pf["probability"].cpu().numpy() - ref["probability"].numpy()).max())
+    assert dp <= 2e-3 and float(np.abs(pf["probability"].cpu().numpy() - pu).max()) <= 2e-3
+    ref_t = onets.dbnet_forward(x[:1], sd, "resnet18", want_threshold=True)["threshold"]
+    assert float((pf["threshold"][:1].cpu() - ref_t).abs().max()) <= 2e-3
+    assert eng_f.macs_per_frame == eng_u.macs_per_frame  # algorithmic count does not depend on the fusion
 
 
 def test_dbnet_batch_independence_and_threshold_branch(r18):

@@ -30,7 +30,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -64,38 +64,59 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int c_off = (c_log >> 2) * p.k_hi_step + (c_log & 3) * 8; // its element offset inside a K-step
     const int howo = p.ho * p.wo;
     const half_t* aptr[A_INST];
+    const half_t* aptr2[CLASSED ? A_INST : 1];
+    // classed mode: a tile is BM entries of the per-image pixel list and carries its own weight class
+    const int cl_img = CLASSED ? tm / p.tiles_per_img : 0;
+    const int cl_lt = CLASSED ? tm - cl_img * p.tiles_per_img : 0;
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-        int m = m0 + (i * NW + w) * 8 + lrow;
-        m = m < p.M ? m : p.M - 1;
-        const int img = m / howo;
-        const int rem = m - img * howo;
-        const int oy = rem / p.wo, ox = rem - oy * p.wo;
-        aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off;
+        if constexpr (CLASSED) {
+            const uint32_t pk = p.plist[cl_lt * BM + (i * NW + w) * 8 + lrow];
+            const int oy = pk == 0xffffffffu ? 0 : (int)(pk & 0xffff), ox = pk == 0xffffffffu ? 0 : (int)(pk >> 16);
+            aptr[i] = p.in + ((int64_t)(cl_img * p.in_hp + oy + p.in_y0) * p.in_wp + ox + p.in_x0) * p.in_c + c_off;
+            aptr2[i] = p.in2 + ((int64_t)(cl_img * p.in2_hp + (oy >> 1) + p.in2_ring - 1) * p.in2_wp + (ox >> 1) + p.in2_ring - 1) * p.in2_c + c_off;
+        } else {
+            int m = m0 + (i * NW + w) * 8 + lrow;
+            m = m < p.M ? m : p.M - 1;
+            const int img = m / howo;
+            const int rem = m - img * howo;
+            const int oy = rem / p.wo, ox = rem - oy * p.wo;
+            aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off;
+        }
     }
+    const half_t* wbase = p.wgt;
+    if constexpr (CLASSED) wbase += (int64_t)p.tile_combo[cl_lt] * p.cout_pad * p.K;
     const half_t* bptr[B_INST];
 #pragma unroll
-    for (int i = 0; i < B_INST; ++i) bptr[i] = p.wgt + (int64_t)(n0 + (i * NW + w) * 8 + lrow) * p.K + c_log * 8;
+    for (int i = 0; i < B_INST; ++i) bptr[i] = wbase + (int64_t)(n0 + (i * NW + w) * 8 + lrow) * p.K + c_log * 8;
 
     // K walk state (scalar): kb = element offset of the current K-step from the tap-(0,0) pixel
     int kb = 0, t_c = 0, t_s = 0;
+    int w_cin = p.cin_steps, w_kw = p.kw, w_s = p.s_step, w_r = p.r_step;
     auto stage = [&](int ks, int buf) {
         char* abase = smem + buf * STAGE;
         char* bbase = abase + A_BYTES;
+        const bool second = CLASSED && ks >= p.seg1_steps;  // wave-uniform
+        if (CLASSED && ks == p.seg1_steps) {  // switch the walk to the second source's 3x3 window
+            kb = 0; t_c = 0; t_s = 0;
+            w_cin = p.cin_steps2; w_kw = p.kw2; w_s = p.s_step2; w_r = p.r_step2;
+        }
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(aptr[i] + kb), (VTD_AS3 void*)(abase + (i * NW + w) * 1024), 16, 0, 0);
+        for (int i = 0; i < A_INST; ++i) {
+            const half_t* src = (second ? aptr2[CLASSED ? i : 0] : aptr[i]) + kb;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (i * NW + w) * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < B_INST; ++i)
             __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64), (VTD_AS3 void*)(bbase + (i * NW + w) * 1024), 16, 0, 0);
         // advance to the next K-step (stages are always issued in K order)
         kb += 64;
-        if (++t_c == p.cin_steps) {
+        if (++t_c == w_cin) {
             t_c = 0;
-            kb += p.s_step - p.cin_steps * 64;
-            if (++t_s == p.kw) {
+            kb += w_s - w_cin * 64;
+            if (++t_s == w_kw) {
                 t_s = 0;
-                kb += p.r_step - p.kw * p.s_step;
+                kb += w_r - w_kw * w_s;
             }
         }
     };
@@ -154,13 +175,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     __syncthreads();  // all waves are done with the staging buffers
     int* pix = (int*)(smem + BM * EPI_ROW);  // [BM][2]: image (or -1 past M), oy | ox << 16
     if (tid < BM) {
-        const int m = m0 + tid;
         int img = -1, oy = 0, ox = 0;
-        if (m < p.M) {
-            img = m / howo;
-            const int rem = m - img * howo;
-            oy = rem / p.wo;
-            ox = rem - oy * p.wo;
+        if constexpr (CLASSED) {
+            const uint32_t pk = p.plist[cl_lt * BM + tid];
+            if (pk != 0xffffffffu) { img = cl_img; oy = (int)(pk & 0xffff); ox = (int)(pk >> 16); }
+        } else {
+            const int m = m0 + tid;
+            if (m < p.M) {
+                img = m / howo;
+                const int rem = m - img * howo;
+                oy = rem / p.wo;
+                ox = rem - oy * p.wo;
+            }
         }
         pix[2 * tid] = img;
         pix[2 * tid + 1] = oy | (ox << 16);
@@ -269,6 +295,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             const floatx4 v1 = *(const floatx4*)(smem + row * EPI_ROW + cc * 32 + 16);
             float v[8] = {v0[0] + bias[0], v0[1] + bias[1], v0[2] + bias[2], v0[3] + bias[3],
                           v1[0] + bias[4], v1[1] + bias[5], v1[2] + bias[6], v1[3] + bias[7]};
+            if constexpr (CLASSED) {  // border-class bias (which taps of the composed window fall inside the image)
+                const int yc = oy == 0 ? 0 : oy == 1 ? 1 : oy == p.img_h - 2 ? 3 : oy == p.img_h - 1 ? 4 : 2;
+                const int xc = ox == 0 ? 0 : ox == 1 ? 1 : ox == p.img_w - 2 ? 3 : ox == p.img_w - 1 ? 4 : 2;
+                const float* bt = p.bias_tab + (yc * 5 + xc) * p.cout + ch;
+                const float4 b0 = *(const float4*)bt, b1 = *(const float4*)(bt + 4);
+                v[0] = v0[0] + b0.x; v[1] = v0[1] + b0.y; v[2] = v0[2] + b0.z; v[3] = v0[3] + b0.w;
+                v[4] = v1[0] + b1.x; v[5] = v1[1] + b1.y; v[6] = v1[2] + b1.z; v[7] = v1[3] + b1.w;
+            }
             if (p.flags & EPI_RESIDUAL) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)resv[it][e];
@@ -298,9 +332,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
 int launch_cfg(const ConvParams& p, hipStream_t stream) {
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;
     const int tiles_n = p.cout_pad / BN;
     constexpr int stage_bytes = STAGES * (BM + BN) * 128;
     constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
@@ -308,11 +342,11 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, STAGES>,
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, stream, p, tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, stream, p, tiles_n);
     return -(int)hipGetLastError();
 }
 
@@ -329,10 +363,12 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //   5   128x64    4     2        48 KB   3      short-K / store-bound layers: more blocks in flight per CU
 //   6   128x64    4     3        72 KB   2
 //   7   64x256    4     2        80 KB   2      only for the fused DB-head tail (EPI_HEAD_FINAL needs all 256 columns)
-int vtd_conv_num_configs() { return 8; }
+//   8/9 128x64    4     2/3               only for the classed dual-source op (pixel-list tiles are 128 rows)
+int vtd_conv_num_configs() { return 10; }
 
 bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
+    if (p.plist) return (cfg == 8 || cfg == 9) && p.cout_pad % 64 == 0;
     switch (cfg) {
         case 0: case 1: case 2: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
@@ -342,6 +378,7 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
 
 int vtd_conv_default_config(const ConvParams& p) {
     if (p.flags & EPI_HEAD_FINAL) return 7;
+    if (p.plist) return 9;
     if (p.cout_pad % 128 == 0) {
         const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * (p.cout_pad / 128);
         return (big_tiles >= 512 && p.K >= 512) ? 0 : 1;
@@ -358,7 +395,9 @@ int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
     if ((p.flags & EPI_PIXEL_SHUFFLE) && (p.ps_cout & 7)) return -1004;
     if (p.ho >= 65536 || p.wo >= 32768) return -1005;
     if ((p.flags & EPI_HEAD_FINAL) && (p.cout != 256 || p.cout_pad != 256 || !p.head_w || !p.prob_out)) return -1008;
-    if (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw))) return -1006;
+    if (p.plist && (!p.tile_combo || !p.in2 || !p.bias_tab || p.tiles_per_img <= 0 || p.M % 128 || p.seg1_steps <= 0 ||
+                    p.cin_steps2 <= 0 || p.kw2 <= 0 || p.stride != 1 || (p.flags & ~EPI_RELU))) return -1009;
+    if (!p.plist && (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw)))) return -1006;
     if (cfg < 0) cfg = vtd_conv_default_config(p);
     if (!vtd_conv_config_valid(p, cfg)) return -1007;
     switch (cfg) {
@@ -369,6 +408,8 @@ int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
         case 4: return launch_cfg<256, 64, 4, 1, 3>(p, stream);
         case 5: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
         case 6: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
-        default: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
+        case 7: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
+        case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
+        default: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
     }
 }

@@ -91,6 +91,12 @@ struct ConvOp {
     int ldc = 0;
     const float* head_w = nullptr;  // EPI_HEAD_FINAL
     float head_b = 0.f;
+    // classed dual-source mode (fused FPN top + head entry)
+    const uint32_t* plist = nullptr;
+    const int* tile_combo = nullptr;
+    int tiles_per_img = 0, seg1_steps = 0, cin_steps2 = 0, kw2 = 0, s_step2 = 0, r_step2 = 0, img_h = 0, img_w = 0;
+    TensorDesc in2;
+    const float* bias_tab = nullptr;
 };
 
 struct Op {
@@ -115,6 +121,13 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     p.res_hp = c.res.hp; p.res_wp = c.res.wp; p.res_ring = c.res.ring; p.res_shift = c.res_shift;
     p.ps_cout = c.ps_cout; p.flags = c.flags; p.ldc = c.ldc;
     p.head_w = c.head_w; p.head_b = c.head_b; p.prob_out = (float*)c.out_f32;
+    if (c.plist) {
+        p.plist = c.plist; p.tile_combo = c.tile_combo; p.tiles_per_img = c.tiles_per_img;
+        p.in2 = c.in2.ptr; p.in2_hp = c.in2.hp; p.in2_wp = c.in2.wp; p.in2_c = c.in2.c; p.in2_ring = c.in2.ring;
+        p.seg1_steps = c.seg1_steps; p.cin_steps2 = c.cin_steps2; p.kw2 = c.kw2; p.s_step2 = c.s_step2; p.r_step2 = c.r_step2;
+        p.bias_tab = c.bias_tab; p.img_h = c.img_h; p.img_w = c.img_w;
+        p.M = n * c.tiles_per_img * 128;
+    }
 }
 
 static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, float* prob_out = nullptr) {
@@ -234,6 +247,7 @@ struct vtd_detector : vtd::ModelBase {
     int64_t macs = 0;
     float* final_out[2] = {nullptr, nullptr};
     std::map<int, std::vector<int>> tuned;  // batch size -> tile config per op (-1 = heuristic)
+    bool fuse_fpn_head = true;  // compose FPN lateral(C2) + top-down add + P2 smooth + head conv into one classed conv
     // optional per-op HIP-event timing (bench / roofline accounting)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -397,6 +411,204 @@ static int build_convt(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDes
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Algebraic fusion of the FPN top and the DB-head entry.  Between C2 / L3 and the head's BatchNorm+ReLU the reference
+// graph is linear:   L2 = Wl*C2 + bl + up2(L3);  P2 = smooth3x3(L2) + bs;  h = head3x3(P2) + bh   (zero padding at each conv)
+// so   h[p] = bias(p) + sum_{u in 5x5} (Wc[u] Wl) C2[p+u] + sum_{u in 5x5} Wc[u] up2(L3)[p+u],   Wc[u] = sum_{t+s=u} Wh[t] Ws[s].
+// The up-sampled term collapses onto the 3x3 neighbourhood of L3 around (y>>1, x>>1) with weights that depend on the
+// pixel's parity; the zero padding of P2 makes Wc (and the bias) depend on which head taps are inside the image.  That
+// gives 16 weight classes (4 row kinds x 4 column kinds) and 25 bias classes; tiles are built from a per-image pixel list so
+// that every tile is of one class.  K = 25*Cin(C2) + 9*256 and N = 64: for R18 3904*64 MACs per pixel instead of
+// 64*256 + 2304*256 + 2304*64 -- the 256-wide P2 map is never formed.
+struct ComposedHeadEntry {
+    std::vector<half_t> w;      // [16][64][K]
+    std::vector<float> bias;    // [25][64]
+    int K = 0;
+};
+
+static int compose_head_entry(const ModelBase* d, const std::string& hp, int c2ch, ComposedHeadEntry& out) {
+    auto Wl = d->get("fpn.inner_blocks.3.weight", (size_t)256 * c2ch), bl = d->get("fpn.inner_blocks.3.bias", 256);
+    auto Ws = d->get("fpn.layer_blocks.3.weight", (size_t)256 * 256 * 9), bs = d->get("fpn.layer_blocks.3.bias", 256);
+    auto Wh = d->get(hp + "0.weight", (size_t)64 * 256 * 9), bh = d->get(hp + "0.bias", 64);
+    if (!Wl || !bl || !Ws || !bs || !Wh || !bh) return ERR_MISSING_KEY;
+    Fold f;
+    int rc = fold_bn(d, hp + "1", "", 64, f);  // BN only: the conv bias is part of the composed bias below
+    if (rc) return rc;
+    const int K = 25 * c2ch + 9 * 256;
+    out.K = K;
+    // G[t][s] = Wh[t] * Ws[s]   (64 x 256), t,s in 3x3
+    std::vector<float> WsT((size_t)9 * 256 * 256), WhT((size_t)9 * 64 * 256);
+    for (int m = 0; m < 256; ++m)
+        for (int c = 0; c < 256; ++c)
+            for (int sI = 0; sI < 9; ++sI) WsT[((size_t)sI * 256 + m) * 256 + c] = (*Ws)[((size_t)m * 256 + c) * 9 + sI];
+    for (int o = 0; o < 64; ++o)
+        for (int m = 0; m < 256; ++m)
+            for (int tI = 0; tI < 9; ++tI) WhT[((size_t)tI * 64 + o) * 256 + m] = (*Wh)[((size_t)o * 256 + m) * 9 + tI];
+    std::vector<float> G((size_t)81 * 64 * 256);
+    std::vector<double> row(256);
+    for (int tI = 0; tI < 9; ++tI)
+        for (int sI = 0; sI < 9; ++sI)
+            for (int o = 0; o < 64; ++o) {
+                std::fill(row.begin(), row.end(), 0.0);
+                const float* wh = &WhT[((size_t)tI * 64 + o) * 256];
+                for (int m = 0; m < 256; ++m) {
+                    const double a = wh[m];
+                    const float* ws = &WsT[((size_t)sI * 256 + m) * 256];
+                    for (int c = 0; c < 256; ++c) row[c] += a * ws[c];
+                }
+                float* g = &G[(((size_t)tI * 9 + sI) * 64 + o) * 256];
+                for (int c = 0; c < 256; ++c) g[c] = (float)row[c];
+            }
+    // hb[t][o] = Wh[t] * bs
+    std::vector<double> hb(9 * 64, 0.0);
+    for (int tI = 0; tI < 9; ++tI)
+        for (int o = 0; o < 64; ++o) {
+            double a = 0;
+            for (int m = 0; m < 256; ++m) a += (double)WhT[((size_t)tI * 64 + o) * 256 + m] * (*bs)[m];
+            hb[tI * 64 + o] = a;
+        }
+    auto tvalid = [](int cls, int t) { return cls == 0 ? t >= 0 : cls == 2 ? t <= 0 : true; };  // cls: 0 first row/col, 1 middle, 2 last
+    out.w.assign((size_t)16 * 64 * K, (half_t)0.f);
+    out.bias.assign(25 * 64, 0.f);
+    std::vector<float> Wc((size_t)25 * 64 * 256);
+    std::vector<double> wb((size_t)9 * 25 * 64, 0.0);  // [class][u][o] = Wc_class[u] * bl
+    for (int cy = 0; cy < 3; ++cy)
+        for (int cx = 0; cx < 3; ++cx) {
+            std::fill(Wc.begin(), Wc.end(), 0.f);
+            for (int ty = -1; ty <= 1; ++ty)
+                for (int tx = -1; tx <= 1; ++tx) {
+                    if (!tvalid(cy, ty) || !tvalid(cx, tx)) continue;
+                    for (int sy = -1; sy <= 1; ++sy)
+                        for (int sx = -1; sx <= 1; ++sx) {
+                            const int u = (ty + sy + 2) * 5 + (tx + sx + 2);
+                            const float* g = &G[((size_t)((ty + 1) * 3 + tx + 1) * 9 + (sy + 1) * 3 + sx + 1) * 64 * 256];
+                            float* wc = &Wc[(size_t)u * 64 * 256];
+                            for (size_t i = 0; i < (size_t)64 * 256; ++i) wc[i] += g[i];
+                        }
+                }
+            const int cls = cy * 3 + cx;
+            for (int u = 0; u < 25; ++u)
+                for (int o = 0; o < 64; ++o) {
+                    double a = 0;
+                    const float* wc = &Wc[((size_t)u * 64 + o) * 256];
+                    for (int c = 0; c < 256; ++c) a += (double)wc[c] * (*bl)[c];
+                    wb[((size_t)cls * 25 + u) * 64 + o] = a;
+                }
+            // C2 part of this class: Wc[u] * Wl  -> [25][64][c2ch]
+            std::vector<float> wc2((size_t)25 * 64 * c2ch);
+            std::vector<double> r2(c2ch);
+            for (int u = 0; u < 25; ++u)
+                for (int o = 0; o < 64; ++o) {
+                    std::fill(r2.begin(), r2.end(), 0.0);
+                    const float* wc = &Wc[((size_t)u * 64 + o) * 256];
+                    for (int c = 0; c < 256; ++c) {
+                        const double a = wc[c];
+                        const float* wl = &(*Wl)[(size_t)c * c2ch];
+                        for (int k = 0; k < c2ch; ++k) r2[k] += a * wl[k];
+                    }
+                    for (int k = 0; k < c2ch; ++k) wc2[((size_t)u * 64 + o) * c2ch + k] = (float)r2[k];
+                }
+            // every (row kind, column kind) combo that uses this class: kinds 0:(first,even) 1:(mid,even) 2:(mid,odd) 3:(last,odd)
+            for (int yk = 0; yk < 4; ++yk)
+                for (int xk = 0; xk < 4; ++xk) {
+                    const int ycls = yk == 0 ? 0 : yk == 3 ? 2 : 1, xcls = xk == 0 ? 0 : xk == 3 ? 2 : 1;
+                    if (ycls != cy || xcls != cx) continue;
+                    const int a = yk >= 2 ? 1 : 0, b = xk >= 2 ? 1 : 0;
+                    half_t* dst = &out.w[(size_t)(yk * 4 + xk) * 64 * K];
+                    for (int o = 0; o < 64; ++o) {
+                        const double sc = f.scale[o];
+                        for (int u = 0; u < 25; ++u)
+                            for (int k = 0; k < c2ch; ++k)
+                                dst[(size_t)o * K + (size_t)u * c2ch + k] = (half_t)(float)(sc * wc2[((size_t)u * 64 + o) * c2ch + k]);
+                        // L3 part: window offset uy lands on L3 row floor((a+uy)/2) (relative to y>>1), likewise columns
+                        std::vector<double> acc((size_t)9 * 256, 0.0);
+                        for (int uy = -2; uy <= 2; ++uy)
+                            for (int ux = -2; ux <= 2; ++ux) {
+                                const int i = (a + uy + 2) / 2 - 1 + 1, j = (b + ux + 2) / 2 - 1 + 1;  // floor((a+uy)/2) + 1 in 0..2
+                                const float* wc = &Wc[((size_t)((uy + 2) * 5 + ux + 2) * 64 + o) * 256];
+                                double* ac = &acc[(size_t)(i * 3 + j) * 256];
+                                for (int c = 0; c < 256; ++c) ac[c] += wc[c];
+                            }
+                        for (int ij = 0; ij < 9; ++ij)
+                            for (int c = 0; c < 256; ++c)
+                                dst[(size_t)o * K + (size_t)25 * c2ch + (size_t)ij * 256 + c] = (half_t)(float)(sc * acc[(size_t)ij * 256 + c]);
+                    }
+                }
+        }
+    // bias classes: y5/x5 in {0: first, 1: second, 2: interior, 3: second-to-last, 4: last}
+    auto inside = [](int c5, int u) { return c5 == 0 ? u >= 0 : c5 == 1 ? u >= -1 : c5 == 3 ? u <= 1 : c5 == 4 ? u <= 0 : true; };
+    for (int y5 = 0; y5 < 5; ++y5)
+        for (int x5 = 0; x5 < 5; ++x5) {
+            const int cy = y5 == 0 ? 0 : y5 == 4 ? 2 : 1, cx = x5 == 0 ? 0 : x5 == 4 ? 2 : 1;
+            for (int o = 0; o < 64; ++o) {
+                double a = (*bh)[o];
+                for (int ty = -1; ty <= 1; ++ty)
+                    for (int tx = -1; tx <= 1; ++tx)
+                        if (tvalid(cy, ty) && tvalid(cx, tx)) a += hb[((ty + 1) * 3 + tx + 1) * 64 + o];
+                for (int uy = -2; uy <= 2; ++uy)
+                    for (int ux = -2; ux <= 2; ++ux)
+                        if (inside(y5, uy) && inside(x5, ux)) a += wb[((size_t)(cy * 3 + cx) * 25 + (uy + 2) * 5 + ux + 2) * 64 + o];
+                out.bias[(y5 * 5 + x5) * 64 + o] = (float)(f.scale[o] * a + f.shift[o]);
+            }
+        }
+    return 0;
+}
+
+// per-image pixel list for the classed op: 16 (row kind x column kind) groups, each padded to whole 128-row tiles
+static void build_pixel_list(int h, int w, std::vector<uint32_t>& plist, std::vector<int>& tile_combo) {
+    auto kind_values = [](int n, int kind) {
+        std::vector<int> v;
+        if (kind == 0) v.push_back(0);
+        else if (kind == 3) v.push_back(n - 1);
+        else for (int i = (kind == 1 ? 2 : 1); i <= n - 2; i += 2) v.push_back(i);
+        return v;
+    };
+    plist.clear();
+    tile_combo.clear();
+    for (int yk = 0; yk < 4; ++yk)
+        for (int xk = 0; xk < 4; ++xk) {
+            const std::vector<int> ys = kind_values(h, yk), xs = kind_values(w, xk);
+            size_t cnt = 0;
+            for (int y : ys)
+                for (int x : xs) { plist.push_back((uint32_t)y | ((uint32_t)x << 16)); ++cnt; }
+            while (cnt % 128) { plist.push_back(0xffffffffu); ++cnt; }
+            for (size_t t = 0; t < cnt / 128; ++t) tile_combo.push_back(yk * 4 + xk);
+        }
+}
+
+static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDesc& c2, const TensorDesc& l3, TensorDesc& out,
+                                    const std::string& hp) {
+    if (c2.ring < 2 || l3.ring < 1 || (c2.c & 63) || l3.c != 256 || c2.h != 2 * l3.h || c2.w != 2 * l3.w || (c2.h & 1) || (c2.w & 1) ||
+        out.h != c2.h || out.w != c2.w || out.c != 64)
+        return ERR_GEOMETRY;
+    ComposedHeadEntry ce;
+    int rc = compose_head_entry(d, hp, c2.c, ce);
+    if (rc) return rc;
+    std::vector<uint32_t> plist;
+    std::vector<int> tile_combo;
+    build_pixel_list(c2.h, c2.w, plist, tile_combo);
+    void *pl = nullptr, *tc = nullptr, *bt = nullptr;
+    if ((rc = upload(d->arena, ce.w.data(), ce.w.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, ce.bias.data(), ce.bias.size() * sizeof(float), &bt))) return rc;
+    if ((rc = upload(d->arena, plist.data(), plist.size() * sizeof(uint32_t), &pl))) return rc;
+    if ((rc = upload(d->arena, tile_combo.data(), tile_combo.size() * sizeof(int), &tc))) return rc;
+    op.bias = (float*)bt;  // first class doubles as the (unused) flat bias
+    op.bias_tab = (const float*)bt;
+    op.plist = (const uint32_t*)pl;
+    op.tile_combo = (const int*)tc;
+    op.tiles_per_img = (int)tile_combo.size();
+    op.in = c2; op.in2 = l3; op.out = out;
+    op.K = ce.K; op.cout = 64; op.cout_pad = 64; op.stride = 1;
+    op.in_y0 = c2.ring - 2; op.in_x0 = c2.ring - 2;
+    op.cin_steps = c2.c / 64; op.kw = 5; op.s_step = c2.c; op.r_step = c2.wp * c2.c; op.k_hi_step = 32;
+    op.seg1_steps = 25 * (c2.c / 64);
+    op.cin_steps2 = 4; op.kw2 = 3; op.s_step2 = 256; op.r_step2 = l3.wp * 256;
+    op.flags = EPI_RELU; op.ho = c2.h; op.wo = c2.w; op.img_h = c2.h; op.img_w = c2.w;
+    op.macs_per_image = (int64_t)c2.h * c2.w * 64 * ce.K;
+    return 0;
+}
+
 static const int kStageWidth[4] = {64, 128, 256, 512};
 
 static int build_detector_graph(vtd_detector* d) {
@@ -405,10 +617,11 @@ static int build_detector_graph(vtd_detector* d) {
     const int* counts = r50 ? counts50 : counts18;
     const int B = d->max_batch;
     int rc;
-    auto new_tensor = [&](int h, int w, int c, TensorDesc& t) {
-        t = make_desc(B, h, w, c, 1, 1);
+    auto new_tensor = [&](int h, int w, int c, TensorDesc& t, int ring = 1) {
+        t = make_desc(B, h, w, c, ring, ring);
         return d->alloc_tensor(t);
     };
+    const bool fuse = d->fuse_fpn_head;
     auto push_conv = [&](const ConvOp& c) {
         Op o;
         o.kind = Op::CONV;
@@ -472,7 +685,7 @@ static int build_detector_graph(vtd_detector* d) {
                 ConvOp c1;
                 if ((rc = build_conv(d, c1, x, t1, pre + ".conv1.weight", f1, cin, width, 3, 3, stride, 1, EPI_RELU))) return rc;
                 push_conv(c1);
-                if ((rc = new_tensor(hout, hout, width, y))) return rc;
+                if ((rc = new_tensor(hout, hout, width, y, (fuse && st == 0 && b == counts[st] - 1) ? 2 : 1))) return rc;
                 if ((rc = fold_bn(d, pre + ".bn2", "", width, f2))) return rc;
                 ConvOp c2;
                 if ((rc = build_conv(d, c2, t1, y, pre + ".conv2.weight", f2, width, width, 3, 3, 1, 1, EPI_RELU | EPI_RESIDUAL))) return rc;
@@ -491,7 +704,7 @@ static int build_detector_graph(vtd_detector* d) {
                 ConvOp c2;
                 if ((rc = build_conv(d, c2, t1, t2, pre + ".conv2.weight", f2, width, width, 3, 3, stride, 1, EPI_RELU))) return rc;
                 push_conv(c2);
-                if ((rc = new_tensor(hout, hout, cout, y))) return rc;
+                if ((rc = new_tensor(hout, hout, cout, y, (fuse && st == 0 && b == counts[st] - 1) ? 2 : 1))) return rc;
                 if ((rc = fold_bn(d, pre + ".bn3", "", cout, f3))) return rc;
                 ConvOp c3;
                 if ((rc = build_conv(d, c3, t2, y, pre + ".conv3.weight", f3, width, cout, 1, 1, 1, 0, EPI_RELU | EPI_RESIDUAL))) return rc;
@@ -507,7 +720,7 @@ static int build_detector_graph(vtd_detector* d) {
 
     // FPN, intended wiring: inner[i] on C5,C4,C3,C2; top-down nearest-2x add fused in the epilogue
     TensorDesc last;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (fuse ? 3 : 4); ++i) {
         const TensorDesc& feat = tapsC[3 - i];
         TensorDesc lat;
         if ((rc = new_tensor(feat.h, feat.w, 256, lat))) return rc;
@@ -521,15 +734,17 @@ static int build_detector_graph(vtd_detector* d) {
         last = lat;
     }
     TensorDesc p2;
-    if ((rc = new_tensor(160, 160, 256, p2))) return rc;
-    {
+    if (!fuse) {
+        if ((rc = new_tensor(160, 160, 256, p2))) return rc;
         Fold f;
         if ((rc = fold_bn(d, "", "fpn.layer_blocks.3.bias", 256, f))) return rc;
         ConvOp c;
         if ((rc = build_conv(d, c, last, p2, "fpn.layer_blocks.3.weight", f, 256, 256, 3, 3, 1, 1, 0))) return rc;
         push_conv(c);
+        d->taps["p2"] = p2;
+    } else if (!d->get("fpn.inner_blocks.3.weight", (size_t)256 * tapsC[0].c) || !d->get("fpn.layer_blocks.3.weight", (size_t)256 * 256 * 9)) {
+        return ERR_MISSING_KEY;
     }
-    d->taps["p2"] = p2;
     // layer_blocks.0..2 exist in checkpoints but their outputs are dead (text_detector.py:56); still validated
     for (int i = 0; i < 3; ++i) {
         const std::string k = "fpn.layer_blocks." + std::to_string(i);
@@ -543,9 +758,14 @@ static int build_detector_graph(vtd_detector* d) {
         TensorDesc h1;
         if ((rc = new_tensor(160, 160, 64, h1))) return rc;
         Fold f1, f2;
-        if ((rc = fold_bn(d, hp + "1", hp + "0.bias", 64, f1))) return rc;
         ConvOp c1;
-        if ((rc = build_conv(d, c1, p2, h1, hp + "0.weight", f1, 256, 64, 3, 3, 1, 1, EPI_RELU))) return rc;
+        if (fuse) {
+            // lateral(C2) + top-down add + P2 smooth + head conv + BN + ReLU as one classed dual-source conv on C2 and L3
+            if ((rc = build_classed_head_entry(d, c1, tapsC[0], last, h1, hp))) return rc;
+        } else {
+            if ((rc = fold_bn(d, hp + "1", hp + "0.bias", 64, f1))) return rc;
+            if ((rc = build_conv(d, c1, p2, h1, hp + "0.weight", f1, 256, 64, 3, 3, 1, 1, EPI_RELU))) return rc;
+        }
         if ((rc = fold_bn(d, hp + "4", hp + "3.bias", 64, f2))) return rc;
         // ConvT(64->64)+BN+ReLU and ConvT(64->1)+sigmoid in one launch: the 64x320x320 intermediate never touches HBM
         ConvOp c2;
@@ -567,7 +787,11 @@ static int build_detector_graph(vtd_detector* d) {
         d->ops.push_back(o1);
         d->ops.push_back(o2);
         if (br == 0) {
-            d->macs += c1.macs_per_image + c2.macs_per_image + (int64_t)320 * 320 * 4 * 64;
+            // macs_per_frame reports the ALGORITHMIC live work of the reference graph, whatever is fused:
+            // lateral(C2) 1x1, P2 smooth 3x3 256->256 and head conv 3x3 256->64 count at their reference size
+            const int64_t px = (int64_t)160 * 160;
+            const int64_t ref_entry = fuse ? px * 256 * tapsC[0].c + px * 256 * 2304 + px * 64 * 2304 : c1.macs_per_image;
+            d->macs += ref_entry + c2.macs_per_image + (int64_t)320 * 320 * 4 * 64;
             d->taps["head1"] = h1;
         }
     }
@@ -697,6 +921,12 @@ int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_
     return 0;
 }
 
+int vtd_detector_set_option(vtd_detector* d, const char* name, int value) {
+    if (!d || !name || d->finalized) return ERR_ARG;
+    if (std::string(name) == "fuse_fpn_head") { d->fuse_fpn_head = value != 0; return 0; }
+    return ERR_UNKNOWN_KEY;
+}
+
 int vtd_detector_finalize(vtd_detector* d, vtd_stream stream) {
     if (!d) return ERR_ARG;
     if (d->finalized) return ERR_ARG;
@@ -804,10 +1034,12 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     const Op& o = d->ops[op_index];
     if (o.kind == Op::CONV) {
         const ConvOp& c = o.conv;
-        static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3"};
+        static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3",
+                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d", cfg >= 0 ? kTile[cfg] : "default", c.ho * c.wo, c.cout, c.K);
+        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 10) ? kTile[cfg] : "default",
+                      c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
     } else {

@@ -59,6 +59,16 @@ struct ConvParams {
     int ps_cout;           // pixel-shuffle: channels per (ky,kx) block
     int flags;
     int ldc;               // EPI_OUT_F32 row stride
+    // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
+    const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
+    const int* tile_combo;   // per local tile: weight class (selects a [cout_pad][K] block of wgt)
+    int tiles_per_img;
+    const half_t* in2;       // second source (L3): gathered at (y>>1, x>>1) - 1
+    int in2_hp, in2_wp, in2_c, in2_ring;
+    int seg1_steps;          // K-steps served by `in` (5x5 window); the rest walk `in2` (3x3 window)
+    int cin_steps2, kw2, s_step2, r_step2;
+    const float* bias_tab;   // [25][cout] border-class bias (y class * 5 + x class)
+    int img_h, img_w;        // extents used for the border classes
     const float* head_w;   // EPI_HEAD_FINAL: [4][64] final ConvT weights (ky2*2+kx2 major), head_b its bias
     float head_b;
     float* prob_out;       // EPI_HEAD_FINAL: [n, 4*ho, 4*wo] float32

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vtd_detector_create": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_detector_destroy": (None, [C.c_void_p]),
     "vtd_detector_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "vtd_detector_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vtd_detector_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtd_detector_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtd_detector_set_input_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -72,7 +72,7 @@ class DeviceFrames:
 class DetectorEngine:
     """DBNet on the GPU: reference checkpoint tensors in, [n,1,640,640] probability maps out."""
 
-    def __init__(self, backbone, state_dict, max_batch=None):
+    def __init__(self, backbone, state_dict, max_batch=None, options=None):
         self.lib = _native.require()
         self.max_batch = max_batch or DEFAULT_MAX_BATCH
         self.backbone = backbone
@@ -81,6 +81,8 @@ class DetectorEngine:
         _native.check(self.lib.vtd_detector_create(backbone.encode(), self.max_batch, C.byref(h)), "vtd_detector_create")
         self.handle = h
         try:
+            for name, value in (options or {}).items():
+                _native.check(self.lib.vtd_detector_set_option(h, name.encode(), int(value)), f"vtd_detector_set_option({name})")
             for key, value in state_dict.items():
                 if key.endswith("num_batches_tracked"):
                     continue
@@ -217,10 +219,10 @@ def records_to_dicts(rec, debug=False):
 def detector_profile(engine):
     """[(description, total_ms, calls, total_macs)] per launch slot of a DetectorEngine (after set_profiling(1))."""
     lib, out = engine.lib, []
-    name = C.create_string_buffer(128)
+    name = C.create_string_buffer(160)
     ms, calls, macs = C.c_double(), C.c_int64(), C.c_double()
     for i in range(lib.vtd_detector_num_ops(engine.handle)):
-        _native.check(lib.vtd_detector_get_profile(engine.handle, i, name, 128, C.byref(ms), C.byref(calls), C.byref(macs),
+        _native.check(lib.vtd_detector_get_profile(engine.handle, i, name, 160, C.byref(ms), C.byref(calls), C.byref(macs),
                                                    _stream_ptr()), "vtd_detector_get_profile")
         out.append((name.value.decode(), ms.value, calls.value, macs.value))
     return out
