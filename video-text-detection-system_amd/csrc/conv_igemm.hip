@@ -311,7 +311,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
-            if (p.flags & EPI_OUT_F32) {
+            if (p.flags & EPI_OUT_F16) {
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+                *(half8*)((half_t*)p.out + (int64_t)(m0 + row) * p.ldc + ch) = hv;
+            } else if (p.flags & EPI_OUT_F32) {
                 float* o = (float*)p.out + (int64_t)(m0 + row) * p.ldc + ch;
                 if (ch + 7 < p.cout) {
                     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -392,6 +397,7 @@ int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
     if (p.M <= 0 || p.K <= 0 || (p.K & 63) || p.cout <= 0 || (p.cout_pad & 63) || p.cout > p.cout_pad) return -1001;
     if ((p.cout & 7) && !(p.flags & EPI_OUT_F32)) return -1002;
     if ((p.flags & EPI_OUT_F32) && (p.ldc & 3)) return -1003;
+    if ((p.flags & EPI_OUT_F16) && ((p.ldc & 7) || (p.cout & 7))) return -1003;
     if ((p.flags & EPI_PIXEL_SHUFFLE) && (p.ps_cout & 7)) return -1004;
     if (p.ho >= 65536 || p.wo >= 32768) return -1005;
     if ((p.flags & EPI_HEAD_FINAL) && (p.cout != 256 || p.cout_pad != 256 || !p.head_w || !p.prob_out)) return -1008;

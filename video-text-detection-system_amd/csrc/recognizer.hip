@@ -138,18 +138,16 @@ __global__ __launch_bounds__(256) void crnn_conv1_pool_kernel(const Conv1Params 
 // non-linearities to its own 16 units x 16 crops in registers (cell state never leaves registers), and
 // writes h_t back to LDS (next step's operand) and to HBM (next layer's input).  One barrier per step.
 struct LstmParams {
-    const float* xs;      // [D*T, 2048] fp32: columns dir*1024 + gate*256 + unit
+    const half_t* xs;     // [D*T, 2048] fp16: columns dir*1024 + gate*256 + unit
     const half_t* whh;    // [2][1024][256] fp16 (dir, gate*256+unit, k)
     half_t* hout;         // [D, T, 512] fp16 (fwd | rev)
     int D, T;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    const float e = __expf(-2.f * fabsf(x));
-    const float t = (1.f - e) / (1.f + e);
-    return x < 0.f ? -t : t;
-}
+// gate non-linearities on the transcendental unit: v_exp_f32 + v_rcp_f32 (each ~1 ulp); an IEEE divide would cost
+// ~10 VALU instructions per gate and the recurrence is latency-bound
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams p) {
     // W_hh of one direction is 512 KB -- exactly one CU's whole register file -- so it cannot be fully resident
@@ -186,24 +184,28 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
 
     const int crop = min(crop0 + fr, p.D - 1);
     const bool live = crop0 + fr < p.D;
+    // The streamed W_hh fragments are issued at the top of a step and consumed by its last 8 MFMAs (24 MFMAs of cover);
+    // the input projection of step s+1 does not depend on h either and is prefetched right after step s's gate maths, so
+    // its HBM latency hides behind the barrier and the next step's MFMAs.  (Prefetching both across the barrier does not
+    // fit the 128-VGPR budget of a 16-wave workgroup.)
+    const half_t* xbase = p.xs + (int64_t)crop * p.T * 2048 + dir * 1024 + wv * 16 + fq * 4;
+    half4 xin[4];
+    {
+        const int t0 = dir ? p.T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = *(const half4*)(xbase + (int64_t)t0 * 2048 + g * 256);
+    }
     for (int step = 0; step < p.T; ++step) {
         const int t = dir ? p.T - 1 - step : step;
         const int cur = step & 1;
-        // streamed fragments first (their addresses do not depend on h)
         half8 ws[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int kc = 6; kc < 8; ++kc) ws[g][kc - 6] = *(const half8*)(wlane + (int64_t)g * 256 * 256 + kc * 32);
-        // input projection x_t W_ih^T + b: loaded now, added after the MFMAs so its HBM latency hides behind them
         floatx4 acc[4];
-        float4 xin[4];
-        const float* xrow = p.xs + ((int64_t)crop * p.T + t) * 2048 + dir * 1024 + wv * 16 + fq * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            xin[g] = *(const float4*)(xrow + g * 256);
-            acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int g = 0; g < 4; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const half8 hf = *(const half8*)(&hbuf[cur][fr][kc * 32 + fq * 8]);
@@ -225,18 +227,17 @@ __global__ __launch_bounds__(1024) void lstm_recurrence_kernel(const LstmParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[g][kc - 6], hf, acc[g], 0, 0, 0);
         }
+        const int tn = dir ? max(t - 1, 0) : min(t + 1, p.T - 1);  // next step's row (clamped: the last prefetch is unused)
         half4 hv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float xi[4] = {j == 0 ? xin[0].x : j == 1 ? xin[0].y : j == 2 ? xin[0].z : xin[0].w,
-                                 j == 0 ? xin[1].x : j == 1 ? xin[1].y : j == 2 ? xin[1].z : xin[1].w,
-                                 j == 0 ? xin[2].x : j == 1 ? xin[2].y : j == 2 ? xin[2].z : xin[2].w,
-                                 j == 0 ? xin[3].x : j == 1 ? xin[3].y : j == 2 ? xin[3].z : xin[3].w};
-            const float ig = sigmoidf_(acc[0][j] + xi[0]), fg = sigmoidf_(acc[1][j] + xi[1]), gg = tanhf_(acc[2][j] + xi[2]),
-                        og = sigmoidf_(acc[3][j] + xi[3]);
+            const float ig = sigmoidf_(acc[0][j] + (float)xin[0][j]), fg = sigmoidf_(acc[1][j] + (float)xin[1][j]),
+                        gg = tanhf_(acc[2][j] + (float)xin[2][j]), og = sigmoidf_(acc[3][j] + (float)xin[3][j]);
             cst[j] = fg * cst[j] + ig * gg;
             hv[j] = (half_t)(og * tanhf_(cst[j]));
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[g] = *(const half4*)(xbase + (int64_t)tn * 2048 + g * 256);
         *(half4*)(&hbuf[cur ^ 1][fr][wv * 16 + fq * 4]) = hv;
         if (live) *(half4*)(p.hout + ((int64_t)crop * p.T + t) * 512 + dir * 256 + wv * 16 + fq * 4) = hv;
         __syncthreads();
@@ -326,7 +327,7 @@ int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float
     return -(int)hipGetLastError();
 }
 
-int vtd_launch_lstm(const float* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s) {
+int vtd_launch_lstm(const half_t* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s) {
     LstmParams p{xs, whh, hout, D, T};
     constexpr int lds = 2 * 16 * 264 * 2 + 16 * 8 * 1024;  // h double buffer + LDS-resident W_hh slice
     static bool attr_done = false;

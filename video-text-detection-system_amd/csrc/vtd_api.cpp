@@ -27,7 +27,7 @@ int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, flo
 
 int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
 int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float* w, const float* bias, half_t* out, int n, hipStream_t s);
-int vtd_launch_lstm(const float* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s);
+int vtd_launch_lstm(const half_t* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s);
 int vtd_launch_ctc_greedy(const float* logits, int n, int T, int V, int ld, const int32_t* id2char, int blank, int apply_softmax,
                           int32_t* out, hipStream_t s);
 int vtd_launch_compact_rows(const float* in, float* out, int64_t rows, int V, int ld, hipStream_t s);
@@ -113,7 +113,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     std::memset(&p, 0, sizeof(p));
     p.in = c.in.ptr; p.wgt = c.w; p.k_hi_step = c.k_hi_step; p.cin_steps = c.cin_steps; p.kw = c.kw; p.s_step = c.s_step; p.r_step = c.r_step; p.bias = c.bias;
     p.res = c.has_res ? c.res.ptr : nullptr;
-    p.out = (c.flags & EPI_OUT_F32) ? c.out_f32 : (void*)c.out.ptr;
+    p.out = (c.flags & (EPI_OUT_F32 | EPI_OUT_F16)) ? c.out_f32 : (void*)c.out.ptr;
     p.M = n * c.ho * c.wo; p.K = c.K; p.cout = c.cout; p.cout_pad = c.cout_pad;
     p.ho = c.ho; p.wo = c.wo;
     p.in_hp = c.in.hp; p.in_wp = c.in.wp; p.in_c = c.in.c; p.in_y0 = c.in_y0; p.in_x0 = c.in_x0; p.stride = c.stride;
@@ -280,7 +280,7 @@ struct vtd_recognizer : vtd::ModelBase {
     TensorDesc t7, h0, h1;
     ConvOp xs_gemm[2], cls_gemm;
     half_t* whh[2] = {nullptr, nullptr};
-    float* xs = nullptr;          // [D*31, 2048]
+    half_t* xs = nullptr;         // [D*31, 2048] fp16 gate pre-activations x W_ih^T + b
     float* logits_pad = nullptr;  // [D*31, 128]
     std::map<std::string, TensorDesc> taps;
     int64_t macs = 0;
@@ -817,7 +817,7 @@ static int read_tensor_nchw(const TensorDesc& t, int n, int creal, float* host_o
 // Dense layer as a 1x1 convolution over a [rows,1,1,K]-shaped view: weights [N][K] (already in GEMM layout),
 // float32 row-major output with leading dimension ldc (LSTM input projections, classifier).
 static int build_linear(ModelBase* d, ConvOp& op, const TensorDesc& in, const std::vector<float>& W, const std::vector<float>& bias,
-                        int N, int K, float* out_f32, int ldc) {
+                        int N, int K, void* out_f32, int ldc, int out_flag = EPI_OUT_F32) {
     if (in.c != K || (K & 63) || (int)W.size() != N * K || (int)bias.size() != N || (ldc & 3) || ldc < N) return ERR_GEOMETRY;
     const int cout_pad = (N + 63) / 64 * 64;
     std::vector<half_t> wp((size_t)cout_pad * K, (half_t)0.f);
@@ -829,7 +829,7 @@ static int build_linear(ModelBase* d, ConvOp& op, const TensorDesc& in, const st
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, b.data(), b.size() * sizeof(float), (void**)&op.bias))) return rc;
     op.in = in; op.out = in; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
-    op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = EPI_OUT_F32; op.ho = in.h; op.wo = in.w;
+    op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = out_flag; op.ho = in.h; op.wo = in.w;
     op.out_f32 = out_f32; op.ldc = ldc;
     op.macs_per_image = (int64_t)in.h * in.w * N * K;
     return 0;
@@ -1133,8 +1133,8 @@ static int build_recognizer_graph(vtd_recognizer* r) {
     r->taps["cnn"] = x;
     const int T = 31;
     // LSTM: hoisted input projections (both directions stacked -> N = 2048) + recurrent weights
-    if ((rc = r->arena.alloc(&p, (size_t)D * T * 2048 * 4, true))) return rc;
-    r->xs = (float*)p;
+    if ((rc = r->arena.alloc(&p, (size_t)D * T * 2048 * sizeof(half_t), true))) return rc;
+    r->xs = (half_t*)p;
     if ((rc = r->arena.alloc(&p, (size_t)D * T * 128 * 4, true))) return rc;
     r->logits_pad = (float*)p;
     r->h0 = make_desc(D, 1, T, 512, 0, 0);
@@ -1154,7 +1154,7 @@ static int build_recognizer_graph(vtd_recognizer* r) {
             for (int i = 0; i < 1024; ++i) B[dir * 1024 + i] = (*bih)[i] + (*bhh)[i];
             for (size_t i = 0; i < (size_t)1024 * 256; ++i) whh[(size_t)dir * 1024 * 256 + i] = (half_t)(*wh)[i];
         }
-        if ((rc = build_linear(r, r->xs_gemm[layer], layer ? r->h0 : r->t7, W, B, 2048, 512, r->xs, 2048))) return rc;
+        if ((rc = build_linear(r, r->xs_gemm[layer], layer ? r->h0 : r->t7, W, B, 2048, 512, r->xs, 2048, EPI_OUT_F16))) return rc;
         if ((rc = upload(r->arena, whh.data(), whh.size() * sizeof(half_t), (void**)&r->whh[layer]))) return rc;
         r->macs += r->xs_gemm[layer].macs_per_image + (int64_t)2 * T * 1024 * 256;
     }
