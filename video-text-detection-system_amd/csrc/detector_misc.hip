@@ -16,6 +16,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int PRE_TY = 16;
 constexpr int PRE_OUT = 640;
+constexpr int PRE_CHUNK = 4;  // raw input rows staged per pass
 
 struct PreParams {
     const uint8_t* frames;  // [n, H, W, 3]
@@ -34,35 +35,56 @@ __device__ __forceinline__ uint8_t clip8_22(int v) {
 }
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];  // [max_rows][640*3]
+    // LDS: [max_rows][640*3] horizontally resampled rows, then a staging area for PRE_CHUNK raw input rows
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
     const int oy0 = blockIdx.x * PRE_TY;
     const int img = blockIdx.y;
     const int y_first = p.yb[2 * oy0];
     const int oy_last = min(oy0 + PRE_TY, PRE_OUT) - 1;
     const int y_end = p.yb[2 * oy_last] + p.yb[2 * oy_last + 1];
     const int nrows = y_end - y_first;
-    const uint8_t* src = p.frames + (int64_t)img * p.H * p.W * 3;
+    const int row_bytes = p.W * 3;
+    const int row_pad = (row_bytes + 15) & ~15;
+    uint8_t* raw = rows + ((p.max_rows * PRE_OUT * 3 + 15) & ~15);
+    const uint8_t* src = p.frames + (int64_t)img * p.H * row_bytes;
 
-    // phase 1: horizontal taps, one (row, ox) per thread-iteration, 3 channels each
-    for (int idx = threadIdx.x; idx < nrows * PRE_OUT; idx += 256) {
-        const int ry = idx / PRE_OUT, ox = idx - ry * PRE_OUT;
-        const uint8_t* row = src + (int64_t)(y_first + ry) * p.W * 3;
-        const int xmin = p.xb[2 * ox], cnt = p.xb[2 * ox + 1];
-        const int* k = p.xk + ox * p.ksx;
-        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
-        for (int t = 0; t < cnt; ++t) {
-            const int kv = k[t];
-            const uint8_t* px = row + (xmin + t) * 3;
-            s0 += px[0] * kv;
-            s1 += px[1] * kv;
-            s2 += px[2] * kv;
+    // phase 1: raw rows -> LDS with the widest loads the row pitch allows (coalesced), then the horizontal taps run
+    // out of LDS; every input row is fetched from HBM once per workgroup
+    for (int r0 = 0; r0 < nrows; r0 += PRE_CHUNK) {
+        const int nr = min(PRE_CHUNK, nrows - r0);
+        if ((row_bytes & 15) == 0) {
+            const int vec_per_row = row_bytes >> 4;
+            for (int i = threadIdx.x; i < nr * vec_per_row; i += 256) {
+                const int rr = i / vec_per_row, v = i - rr * vec_per_row;
+                *(uint4*)(raw + rr * row_pad + v * 16) = *(const uint4*)(src + (int64_t)(y_first + r0 + rr) * row_bytes + v * 16);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nr * row_bytes; i += 256) {
+                const int rr = i / row_bytes, v = i - rr * row_bytes;
+                raw[rr * row_pad + v] = src[(int64_t)(y_first + r0 + rr) * row_bytes + v];
+            }
         }
-        uint8_t* d = rows + (ry * PRE_OUT + ox) * 3;
-        d[0] = clip8_22(s0);
-        d[1] = clip8_22(s1);
-        d[2] = clip8_22(s2);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nr * PRE_OUT; idx += 256) {
+            const int rr = idx / PRE_OUT, ox = idx - rr * PRE_OUT;
+            const uint8_t* row = raw + rr * row_pad;
+            const int xmin = p.xb[2 * ox], cnt = p.xb[2 * ox + 1];
+            const int* k = p.xk + ox * p.ksx;
+            int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+            for (int t = 0; t < cnt; ++t) {
+                const int kv = k[t];
+                const uint8_t* px = row + (xmin + t) * 3;
+                s0 += px[0] * kv;
+                s1 += px[1] * kv;
+                s2 += px[2] * kv;
+            }
+            uint8_t* d = rows + ((r0 + rr) * PRE_OUT + ox) * 3;
+            d[0] = clip8_22(s0);
+            d[1] = clip8_22(s1);
+            d[2] = clip8_22(s2);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // phase 2: vertical taps + normalise; input channel order is BGR, output RGB0
     const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(256) void final_convt_sigmoid_kernel(const FinalPar
 int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
                           const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream) {
     PreParams p{frames, out, xb, xk, yb, yk, H, W, ksx, ksy, max_rows};
-    const int lds = max_rows * PRE_OUT * 3;
+    const int lds = ((max_rows * PRE_OUT * 3 + 15) & ~15) + PRE_CHUNK * ((W * 3 + 15) & ~15);
     if (lds > 160 * 1024) return -1010;
     static bool attr_done = false;
     if (!attr_done) {

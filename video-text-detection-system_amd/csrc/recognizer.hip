@@ -70,24 +70,23 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const CropParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ K7a
-// conv1 (K = 27) is far too thin for MFMA: fp32 FMAs, weights in LDS, the 2x2 max-pool fused in.
-// One workgroup = one pooled output row of one crop: 64 pooled pixels x 64 channels; thread = pooled pixel x 16 ch.
+// conv1 3x3 (3 -> 64, K = 27 padded to 32) + BN + ReLU + 2x2 max-pool in one launch.  One workgroup = one pooled output
+// row of one crop = 2 conv rows x 128 px = 256 GEMM rows.  The im2col tile [256][32] fp16 is built in LDS with the rows
+// ordered so that the four members of a pool window sit at the same lane position of a wave's four M-fragments: the
+// 2x2 max is then an element-wise max of four accumulator registers -- no shuffles, no second pass.
 struct Conv1Params {
     const uint8_t* in_u8;   // [n,32,128,3] uint8 (scaled by 1/255 here) or NULL
     const float* in_f32;    // [n,3,32,128] float32 (reference-format tensor) or NULL
-    const float* w;         // [64][27] BN-folded, k = (r*3+s)*3 + c
+    const half_t* w;        // [64][32] fp16 BN-folded, k = (r*3+s)*3 + c, k >= 27 zero
     const float* bias;      // [64]
     half_t* out;            // [n, 16+2, 64+2, 64] ring 1
     int n;
 };
 
 __global__ __launch_bounds__(256) void crnn_conv1_pool_kernel(const Conv1Params p) {
-    __shared__ float wsh[64 * 27];
-    __shared__ float bsh[64];
-    __shared__ float tile[4][130][3];  // input rows 2*py-1 .. 2*py+2, columns -1..128, zero padded
+    __shared__ __attribute__((aligned(16))) half_t atile[256 * 32];  // swizzled: 16-byte chunk c of row r at c ^ ((r>>2)&3)
+    __shared__ half_t tile[4][130][4];                                // input rows 2*py-1 .. 2*py+2, columns -1..128, zero padded
     const int crop = blockIdx.y, py = blockIdx.x;
-    for (int i = threadIdx.x; i < 64 * 27; i += 256) wsh[i] = p.w[i];
-    if (threadIdx.x < 64) bsh[threadIdx.x] = p.bias[threadIdx.x];
     for (int i = threadIdx.x; i < 4 * 130 * 3; i += 256) {
         const int c = i % 3, xx = (i / 3) % 130, r = i / (3 * 130);
         const int y = 2 * py - 1 + r, x = xx - 1;
@@ -96,38 +95,57 @@ __global__ __launch_bounds__(256) void crnn_conv1_pool_kernel(const Conv1Params 
             if (p.in_u8) v = (float)p.in_u8[(((int64_t)crop * 32 + y) * 128 + x) * 3 + c] / 255.0f;
             else v = p.in_f32[(((int64_t)crop * 3 + c) * 32 + y) * 128 + x];
         }
-        tile[r][xx][c] = v;
+        tile[r][xx][c] = (half_t)v;
     }
     __syncthreads();
-    const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    float best[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) best[j] = 0.f;  // post-ReLU values are >= 0
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-        const int oy = sub >> 1, ox = 2 * px + (sub & 1);
-        float patch[27];
+    {   // thread t builds GEMM row t: wave w = t>>6 owns pooled pixels 16w..16w+15; row = w*64 + member*16 + window
+        const int t = threadIdx.x, w = t >> 6, member = (t >> 4) & 3, win = t & 15;
+        const int oy = member >> 1, ox = 2 * (w * 16 + win) + (member & 1);
+        half_t vals[32];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) patch[(r * 3 + s) * 3 + c] = tile[oy + r][ox + s][c];
+                for (int c = 0; c < 3; ++c) vals[(r * 3 + s) * 3 + c] = tile[oy + r][ox + s][c];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int ch = cg * 16 + j;
-            float acc = bsh[ch];
+        for (int k = 27; k < 32; ++k) vals[k] = (half_t)0.f;
 #pragma unroll
-            for (int k = 0; k < 27; ++k) acc += patch[k] * wsh[ch * 27 + k];
-            best[j] = fmaxf(best[j], acc);
+        for (int ck = 0; ck < 4; ++ck) {
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vals[ck * 8 + e];
+            *(half8*)(atile + t * 32 + ((ck ^ ((t >> 2) & 3)) * 8)) = v;
         }
     }
-    half_t* o = p.out + (((int64_t)crop * 18 + py + 1) * 66 + px + 1) * 64 + cg * 16;
-    half8 h0, h1;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    floatx4 acc[4][4];  // [channel tile][pool member]
+    half8 wf[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { h0[j] = (half_t)best[j]; h1[j] = (half_t)best[8 + j]; }
-    *(half8*)o = h0;
-    *(half8*)(o + 8) = h1;
+    for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(p.w + (i * 16 + fr) * 32 + fq * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wv * 64 + j * 16 + fr;
+        const half8 af = *(const half8*)(atile + row * 32 + ((fq ^ ((row >> 2) & 3)) * 8));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // lane: channels i*16 + fq*4 .. +4 of pooled pixel 16wv + fr; max over the four members, then bias + ReLU (monotone)
+    half_t* o = p.out + (((int64_t)crop * 18 + py + 1) * 66 + wv * 16 + fr + 1) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 bv = *(const float4*)(p.bias + i * 16 + fq * 4);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m = fmaxf(fmaxf(acc[i][0][e], acc[i][1][e]), fmaxf(acc[i][2][e], acc[i][3][e])) + bb[e];
+            hv[e] = (half_t)(m > 0.f ? m : 0.f);
+        }
+        *(half4*)(o + i * 16 + fq * 4) = hv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K8
@@ -321,7 +339,7 @@ int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* b
     return -(int)hipGetLastError();
 }
 
-int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float* w, const float* bias, half_t* out, int n, hipStream_t s) {
+int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const half_t* w, const float* bias, half_t* out, int n, hipStream_t s) {
     Conv1Params p{in_u8, in_f32, w, bias, out, n};
     hipLaunchKernelGGL(crnn_conv1_pool_kernel, dim3(16, n), dim3(256), 0, s, p);
     return -(int)hipGetLastError();

@@ -26,7 +26,7 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
 int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
 
 int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
-int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const float* w, const float* bias, half_t* out, int n, hipStream_t s);
+int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const half_t* w, const float* bias, half_t* out, int n, hipStream_t s);
 int vtd_launch_lstm(const half_t* xs, const half_t* whh, half_t* hout, int D, int T, hipStream_t s);
 int vtd_launch_ctc_greedy(const float* logits, int n, int T, int V, int ld, const int32_t* id2char, int blank, int apply_softmax,
                           int32_t* out, hipStream_t s);
@@ -274,7 +274,8 @@ struct vtd_recognizer : vtd::ModelBase {
     int vocab = 0, max_crops = 0;
     bool finalized = false;
     uint8_t* resized = nullptr;   // [D,32,128,3] K6 output
-    float *w1 = nullptr, *b1 = nullptr;  // conv1 fp32 [64][27], [64]
+    half_t* w1 = nullptr;         // conv1 fp16 [64][32] (K = 27 padded)
+    float* b1 = nullptr;          // [64]
     TensorDesc t1;
     std::vector<Op> ops;          // conv2 .. conv7 with their pools
     TensorDesc t7, h0, h1;
@@ -1086,15 +1087,16 @@ static int build_recognizer_graph(vtd_recognizer* r) {
         if ((rc = fold_bn(r, "cnn.1", "cnn.0.bias", 64, f))) return rc;
         auto w = r->get("cnn.0.weight", 64 * 3 * 3 * 3);
         if (!w) return ERR_MISSING_KEY;
-        std::vector<float> wp(64 * 27), bp(64);
+        std::vector<half_t> wp(64 * 32, (half_t)0.f);
+        std::vector<float> bp(64);
         for (int co = 0; co < 64; ++co) {
             bp[co] = (float)f.shift[co];
             for (int c = 0; c < 3; ++c)
                 for (int rr = 0; rr < 3; ++rr)
                     for (int ss = 0; ss < 3; ++ss)
-                        wp[co * 27 + (rr * 3 + ss) * 3 + c] = (float)((double)(*w)[((co * 3 + c) * 3 + rr) * 3 + ss] * f.scale[co]);
+                        wp[co * 32 + (rr * 3 + ss) * 3 + c] = (half_t)(float)((double)(*w)[((co * 3 + c) * 3 + rr) * 3 + ss] * f.scale[co]);
         }
-        if ((rc = upload(r->arena, wp.data(), wp.size() * 4, (void**)&r->w1))) return rc;
+        if ((rc = upload(r->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&r->w1))) return rc;
         if ((rc = upload(r->arena, bp.data(), bp.size() * 4, (void**)&r->b1))) return rc;
         if ((rc = new_tensor(16, 64, 64, 1, r->t1))) return rc;
         r->macs += (int64_t)32 * 128 * 64 * 27;
