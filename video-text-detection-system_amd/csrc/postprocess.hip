@@ -32,10 +32,12 @@ struct PostWs {
     int n, h, w, P;
     float thr;
     int* label;        // [n][P+1], index 0 = frame background sentinel, pixel i <-> i+1
-    uint8_t* flags;    // [n][P]  bit0 foreground, bit1 inside (not frame background)
+    uint64_t* fgbits;  // [n][h][wpr] foreground, 1 bit per pixel
+    uint64_t* inbits;  // [n][h][wpr] inside (foreground or hole: not frame background)
+    int wpr;           // 64-pixel words per row
     int* compid;       // [n][P]  valid at component roots
     int* ncomp;        // [n]
-    int* slice_count;  // [n][ceil(P/64)] roots per 64-pixel slice, then their exclusive prefix
+    int* slice_count;  // [n][h*wpr] roots per word, then their exclusive prefix
     int maxc;          // capacity of the per-component arrays
     int* area2;        // [n][maxc]  2 * contour area
     int* bbox;         // [n][maxc][4] xmin,xmax,ymin,ymax
@@ -80,20 +82,47 @@ __device__ __forceinline__ void uf_unite(int* L, int a, int b) {
     }
 }
 
-// ---- stage 1: threshold + horizontal runs.  One wave owns 64 consecutive pixels of one row: a ballot of the
-// foreground bit gives every lane the start of its same-class run inside the segment, which becomes its
-// initial union-find parent.  Horizontal connectivity therefore costs no atomics at all, and the (usually
-// huge) frame background collapses to one run per row segment instead of one node per pixel.
+// The per-pixel stages work on bit-packed rows: one 64-bit word = 64 consecutive pixels of a row (`wpr` words per row),
+// one thread per word.  Neighbour tests are shifts/ANDs of the word, the row above and their edge carries; only the set
+// bits of the resulting masks (run contacts, class changes) touch the union-find.
+struct Words3 { uint64_t c, l, r; };
+__device__ __forceinline__ Words3 load3(const uint64_t* B, int y, int seg, int h, int wpr) {
+    Words3 o{0, 0, 0};
+    if (y < 0 || y >= h) return o;
+    const uint64_t* row = B + (int64_t)y * wpr;
+    o.c = row[seg];
+    o.l = seg > 0 ? row[seg - 1] : 0;
+    o.r = seg + 1 < wpr ? row[seg + 1] : 0;
+    return o;
+}
+__device__ __forceinline__ uint64_t west(const Words3& v) { return (v.c << 1) | (v.l >> 63); }   // bit i = pixel i-1
+__device__ __forceinline__ uint64_t east(const Words3& v) { return (v.c >> 1) | (v.r << 63); }   // bit i = pixel i+1
+__device__ __forceinline__ uint64_t valid_mask(int seg, int w, int wpr) {
+    return (seg == wpr - 1 && (w & 63)) ? ((1ull << (w & 63)) - 1ull) : ~0ull;
+}
+// lowest maximal run of ones in m: returns its mask, start in *i0, length in *len
+__device__ __forceinline__ uint64_t first_run(uint64_t m, int* i0, int* len) {
+    const int i = __ffsll((long long)m) - 1;
+    const uint64_t t = m >> i;
+    const int n = (~t == 0) ? 64 - i : __ffsll((long long)~t) - 1;
+    *i0 = i;
+    *len = n;
+    return (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << i;
+}
+
+// ---- stage 1: threshold + horizontal runs.  One wave owns one word: a ballot of the foreground bit is the packed word
+// and gives every lane the start of its same-class run inside the word, which becomes its initial union-find parent.
+// Horizontal connectivity therefore costs no atomics at all, and the (usually huge) frame background collapses to one
+// run per word instead of one node per pixel.
 __global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
     const int lane = threadIdx.x & 63;
-    const int segs = (ws.w + 63) >> 6;
-    const int64_t total = (int64_t)ws.n * ws.h * segs;
+    const int64_t total = (int64_t)ws.n * ws.h * ws.wpr;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t wi = wave0; wi < total; wi += nwaves) {
-        const int f = (int)(wi / ((int64_t)ws.h * segs));
-        const int rem = (int)(wi - (int64_t)f * ws.h * segs);
-        const int y = rem / segs, seg = rem - y * segs;
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
         const int x = seg * 64 + lane;
         const bool valid = x < ws.w;
         const int pix = y * ws.w + x;
@@ -108,92 +137,114 @@ __global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
             // background on the frame's border belongs to the (virtual) outside: hang it on the sentinel
             if (!fg && (y == 0 || y == ws.h - 1 || x == 0)) parent = 0;
             L[pix + 1] = parent;
-            ws.flags[(int64_t)f * ws.P + pix] = fg ? 1 : 0;
         }
-        if (wi == (int64_t)f * ws.h * segs && lane == 0) ws.label[(int64_t)f * (ws.P + 1)] = 0;
+        if (lane == 0) {
+            ws.fgbits[wi] = m;
+            if (rem == 0) ws.label[(int64_t)f * (ws.P + 1)] = 0;
+        }
     }
 }
+
+#define PP_FOR_EACH_WORD(f, y, seg, wi)                                                                            \
+    const int64_t total_words = (int64_t)ws.n * ws.h * ws.wpr;                                                     \
+    for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < total_words; wi += (int64_t)gridDim.x * blockDim.x)
 
 // ---- stage 2: join runs.  Only the first column of every run-to-run contact issues a union.
 __global__ void pp_merge_fg_bg(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        const int y = pix / ws.w, x = pix - y * ws.w;
-        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const uint64_t* B = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
         int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const int me = F[pix] & 1;
-        const int W = x > 0 ? (F[pix - 1] & 1) : -1;
-        if ((x & 63) == 0 && W == me) uf_unite(L, pix + 1, pix);  // run continues across a 64-pixel segment seam
-        if (!me && x == ws.w - 1) uf_unite(L, pix + 1, 0);          // background touching the right frame edge
+        const uint64_t vm = valid_mask(seg, ws.w, ws.wpr);
+        const Words3 cur = load3(B, y, seg, ws.h, ws.wpr), up = load3(B, y - 1, seg, ws.h, ws.wpr);
+        const int base = y * ws.w + seg * 64 + 1;  // label index of bit 0
+        if (seg > 0 && (int)(cur.c & 1) == (int)(cur.l >> 63)) uf_unite(L, base, base - 1);  // run continues across the word seam
+        if (seg == ws.wpr - 1 && !((cur.c >> ((ws.w - 1) & 63)) & 1)) uf_unite(L, base + ((ws.w - 1) & 63), 0);  // background at the right frame edge
         if (y == 0) continue;
-        const int N = F[pix - ws.w] & 1;
-        const int NW = x > 0 ? (F[pix - ws.w - 1] & 1) : -1;
-        if (me) {  // foreground: 8-connected
-            if (N) {
-                if (!(W == 1 && NW == 1)) uf_unite(L, pix + 1, pix - ws.w + 1);
-            } else {
-                if (NW == 1 && W != 1) uf_unite(L, pix + 1, pix - ws.w);
-                if (x < ws.w - 1 && (F[pix - ws.w + 1] & 1) && !(F[pix + 1] & 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
-            }
-        } else if (!N) {  // background: 4-connected
-            if (!(W == 0 && NW == 0)) uf_unite(L, pix + 1, pix - ws.w + 1);
-        }
+        const uint64_t W = west(cur), E = east(cur), N = up.c, NW = west(up), NE = east(up);
+        // foreground, 8-connected
+        uint64_t m = cur.c & N & ~(W & NW);
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+        m = cur.c & ~N & NW & ~W;
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
+        m = cur.c & ~N & NE & ~E;
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
+        // background, 4-connected (pixels left of the frame do not exist: bit 0 of word 0 has no west neighbour)
+        const uint64_t bg = ~cur.c & vm, bgN = ~up.c & vm;
+        const uint64_t bgW = (~cur.c << 1) | (seg > 0 ? (~cur.l) >> 63 : 0), bgNW = (~up.c << 1) | (seg > 0 ? (~up.l) >> 63 : 0);
+        m = bg & bgN & ~(bgW & bgNW);
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
     }
 }
 
+// ---- stage 3a: background runs that do not reach the frame background are holes -> inside mask
 __global__ void pp_classify(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const uint8_t fl = ws.flags[i];
-        bool inside = fl & 1;
-        if (!inside) inside = uf_find(L, pix + 1) != 0;  // background not connected to the frame = hole
-        ws.flags[i] = (uint8_t)((fl & 1) | (inside ? 2 : 0));
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const uint64_t cur = ws.fgbits[wi];
+        uint64_t bg = ~cur & valid_mask(seg, ws.w, ws.wpr), holes = 0;
+        const int base = y * ws.w + seg * 64 + 1;
+        while (bg) {
+            int i0, len;
+            const uint64_t run = first_run(bg, &i0, &len);
+            if (uf_find(L, base + i0) != 0) holes |= run;
+            bg &= ~run;
+        }
+        ws.inbits[wi] = cur | holes;
     }
 }
 
-// ---- stage 3: filled components = foreground + holes + islands.  Same-class neighbours are already joined
-// (diagonal hole pixels always share a 4-connected or foreground bridge), so only class changes need unions.
+// ---- stage 3b: filled components = foreground + holes + islands.  Same-class neighbours are already joined (diagonal
+// hole pixels always share a 4-connected or foreground bridge), so only class changes need unions.
 __global__ void pp_merge_inside(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
-        const int me = F[pix];
-        if (!(me & 2)) continue;
-        const int y = pix / ws.w, x = pix - y * ws.w;
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const uint64_t* F = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
+        const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
         int* L = ws.label + (int64_t)f * (ws.P + 1);
-        auto other = [&](int q) { const int v = F[q]; return (v & 2) && ((v ^ me) & 1); };
-        if (x > 0 && other(pix - 1)) uf_unite(L, pix + 1, pix);
-        if (y > 0) {
-            if (other(pix - ws.w)) uf_unite(L, pix + 1, pix - ws.w + 1);
-            if (x > 0 && other(pix - ws.w - 1)) uf_unite(L, pix + 1, pix - ws.w);
-            if (x < ws.w - 1 && other(pix - ws.w + 1)) uf_unite(L, pix + 1, pix - ws.w + 2);
-        }
+        const Words3 fc = load3(F, y, seg, ws.h, ws.wpr), fu = load3(F, y - 1, seg, ws.h, ws.wpr);
+        const Words3 ic = load3(I, y, seg, ws.h, ws.wpr), iu = load3(I, y - 1, seg, ws.h, ws.wpr);
+        if (!ic.c) continue;
+        const int base = y * ws.w + seg * 64 + 1;
+        uint64_t m = ic.c & west(ic) & (fc.c ^ west(fc));
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - 1); }
+        m = ic.c & iu.c & (fc.c ^ fu.c);
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+        m = ic.c & west(iu) & (fc.c ^ west(fu));
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
+        m = ic.c & east(iu) & (fc.c ^ east(fu));
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
     }
 }
 
-// ---- stage 4: flatten + count component roots per 64-pixel wave slice (coalesced)
-__global__ __launch_bounds__(256) void pp_flatten_count(const PostWs ws) {
-    const int lane = threadIdx.x & 63;
-    const int slices = (ws.P + 63) >> 6;
-    const int64_t total = (int64_t)ws.n * slices;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t wi = wave0; wi < total; wi += nwaves) {
-        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
-        const int pix = sl * 64 + lane;
-        bool root = false;
-        if (pix < ws.P && (ws.flags[(int64_t)f * ws.P + pix] & 2)) {
-            int* L = ws.label + (int64_t)f * (ws.P + 1);
-            const int r = uf_find(L, pix + 1);
-            L[pix + 1] = r;
-            root = r == pix + 1;
+// ---- stage 4: component roots.  A root is the raster-first pixel of its filled component, hence a foreground run start;
+// only those are examined (and path-compressed), counted per word, scanned per frame and numbered in raster order.
+__device__ __forceinline__ uint64_t fg_run_starts(uint64_t cur) { return cur & ~(cur << 1); }
+
+__global__ void pp_count_roots(const PostWs ws) {
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const int base = y * ws.w + seg * 64 + 1;
+        uint64_t m = fg_run_starts(ws.fgbits[wi]);
+        int cnt = 0;
+        while (m) {
+            const int i = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int r = uf_find(L, base + i);
+            L[base + i] = r;
+            cnt += r == base + i;
         }
-        const unsigned long long m = __ballot(root);
-        if (lane == 0) ws.slice_count[(int64_t)f * slices + sl] = __popcll(m);
+        ws.slice_count[wi] = cnt;
     }
 }
 
@@ -215,11 +266,11 @@ __device__ int block_exclusive_scan(int v, int* sh /* [2*SCAN_THREADS] */, int* 
     return incl - v;
 }
 
-// one block per frame: exclusive scan of the slice counts (raster order), reset the per-component accumulators
+// one block per frame: exclusive scan of the per-word root counts (raster order), reset the per-component accumulators
 __global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) {
     __shared__ int sh[2 * SCAN_THREADS];
     const int f = blockIdx.x;
-    const int slices = (ws.P + 63) >> 6;
+    const int slices = ws.h * ws.wpr;
     int* cnt = ws.slice_count + (int64_t)f * slices;
     const int chunk = (slices + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(threadIdx.x * chunk, slices), hi = min(lo + chunk, slices);
@@ -241,90 +292,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) 
     }
 }
 
-// number the components by raster order of their root (= raster-first pixel of the component)
-__global__ __launch_bounds__(256) void pp_number_components(const PostWs ws) {
-    const int lane = threadIdx.x & 63;
-    const int slices = (ws.P + 63) >> 6;
-    const int64_t total = (int64_t)ws.n * slices;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t wi = wave0; wi < total; wi += nwaves) {
-        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
-        const int pix = sl * 64 + lane;
-        const bool root = pix < ws.P && (ws.flags[(int64_t)f * ws.P + pix] & 2) &&
-                          ws.label[(int64_t)f * (ws.P + 1) + pix + 1] == pix + 1;
-        const unsigned long long m = __ballot(root);
-        if (root) ws.compid[(int64_t)f * ws.P + pix] = ws.slice_count[(int64_t)f * slices + sl] +
-                                                         __popcll(m & ((1ull << lane) - 1ull));
+__global__ void pp_number_components(const PostWs ws) {
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const int base = y * ws.w + seg * 64 + 1;
+        uint64_t m = fg_run_starts(ws.fgbits[wi]);
+        int next = ws.slice_count[wi];
+        while (m) {
+            const int i = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (L[base + i] == base + i) ws.compid[(int64_t)f * ws.P + base + i - 1] = next++;
+        }
     }
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
-}
-
-// ---- stage 5: per-component contour area (lattice identity) and bounding box.  A wave's 64 consecutive pixels
-// nearly always belong to one or two components, so contributions are combined per component inside the wave and
-// one lane issues the atomics.
-__global__ __launch_bounds__(256) void pp_stats(const PostWs ws) {
-    const int lane = threadIdx.x & 63;
-    const int slices = (ws.P + 63) >> 6;
-    const int64_t total = (int64_t)ws.n * slices;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t wi = wave0; wi < total; wi += nwaves) {
-        const int f = (int)(wi / slices), sl = (int)(wi - (int64_t)f * slices);
-        const int pix = sl * 64 + lane;
-        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
+// ---- stage 5: per-component contour area (lattice identity) and bounding box, one set of atomics per inside run.
+// 2x2 blocks are anchored at their top-left pixel and credited to the run that owns the block's first inside pixel of the
+// top row (every block with >= 3 inside pixels has one).
+__global__ void pp_stats(const PostWs ws) {
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
+        const Words3 a = load3(I, y, seg, ws.h, ws.wpr);
+        if (!a.c) continue;
+        const Words3 b = load3(I, y + 1, seg, ws.h, ws.wpr);
         const int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const int* cid = ws.compid + (int64_t)f * ws.P;
-        int comp = -1, add = 0, ex0 = 0x7fffffff, ex1 = -1, ey0 = 0x7fffffff, ey1 = -1;
-        if (pix < ws.P) {
-            const int y = pix / ws.w, x = pix - y * ws.w;
-            const bool in00 = F[pix] & 2;
-            int cnt = 0, any = -1;
-            if (x < ws.w - 1 && y < ws.h - 1) {
-                const bool in10 = F[pix + 1] & 2, in01 = F[pix + ws.w] & 2, in11 = F[pix + ws.w + 1] & 2;
-                cnt = (int)in00 + (int)in10 + (int)in01 + (int)in11;
-                any = in00 ? pix : pix + 1;  // with >= 3 of 4 set, one of the top two is set
-            }
-            if (in00) {
-                comp = cid[L[pix + 1] - 1];
-                const bool edge = x == 0 || y == 0 || x == ws.w - 1 || y == ws.h - 1 || !(F[pix - 1] & 2) || !(F[pix + 1] & 2) ||
-                                  !(F[pix - ws.w] & 2) || !(F[pix + ws.w] & 2);
-                if (edge) { ex0 = ex1 = x; ey0 = ey1 = y; }
-            } else if (cnt >= 3) {
-                comp = cid[L[any + 1] - 1];
-            }
-            if (cnt >= 3) add = cnt == 4 ? 2 : 1;
-        }
-        bool pending = comp >= 0 && (add != 0 || ex1 >= 0);
-        unsigned long long pm = __ballot(pending);
-        while (pm) {
-            const int leader = __ffsll((long long)pm) - 1;
-            const int lc = __shfl(comp, leader);
-            const bool mine = pending && comp == lc;
-            const int s = wave_sum(mine ? add : 0);
-            const int a0 = wave_min(mine ? ex0 : 0x7fffffff), a1 = wave_max(mine ? ex1 : -1);
-            const int b0 = wave_min(mine ? ey0 : 0x7fffffff), b1 = wave_max(mine ? ey1 : -1);
-            if (lane == leader) {
-                if (s) atomicAdd(ws.area2 + (int64_t)f * ws.maxc + lc, s);
-                if (a1 >= 0) {
-                    int* bb = ws.bbox + ((int64_t)f * ws.maxc + lc) * 4;
-                    atomicMin(bb + 0, a0); atomicMax(bb + 1, a1); atomicMin(bb + 2, b0); atomicMax(bb + 3, b1);
-                }
-            }
-            pending = pending && !mine;
-            pm = __ballot(pending);
+        const uint64_t a1 = east(a), b1 = east(b);
+        const uint64_t four = a.c & a1 & b.c & b1;
+        const uint64_t three = (a.c & a1 & b.c & ~b1) | (a.c & a1 & ~b.c & b1) | (a.c & ~a1 & b.c & b1) | (~a.c & a1 & b.c & b1);
+        // block anchored on the last pixel of the previous word whose only missing corner is that pixel: owned by bit 0 here
+        const int carry = (seg > 0 && !(a.l >> 63) && (a.c & 1) && (b.l >> 63) && (b.c & 1)) ? 1 : 0;
+        const int base = y * ws.w + seg * 64 + 1;
+        uint64_t m = a.c;
+        while (m) {
+            int i0, len;
+            const uint64_t run = first_run(m, &i0, &len);
+            m &= ~run;
+            const uint64_t left = i0 > 0 ? 1ull << (i0 - 1) : 0ull;
+            const int add = 2 * __popcll(four & run) + __popcll(three & (run | left)) + (i0 == 0 ? carry : 0);
+            const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
+            if (add) atomicAdd(ws.area2 + (int64_t)f * ws.maxc + c, add);
+            int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
+            atomicMin(bb + 0, seg * 64 + i0); atomicMax(bb + 1, seg * 64 + i0 + len - 1); atomicMin(bb + 2, y); atomicMax(bb + 3, y);
         }
     }
 }
@@ -364,20 +378,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
 }
 
 __global__ void pp_row_extents(const PostWs ws) {
-    const int64_t total = (int64_t)ws.n * ws.P;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i / ws.P), pix = (int)(i - (int64_t)f * ws.P);
-        const uint8_t* F = ws.flags + (int64_t)f * ws.P;
-        if (!(F[pix] & 2)) continue;
-        const int y = pix / ws.w, x = pix - y * ws.w;
-        const bool left = x == 0 || !(F[pix - 1] & 2), right = x == ws.w - 1 || !(F[pix + 1] & 2);
-        if (!left && !right) continue;
-        const int c = ws.compid[(int64_t)f * ws.P + ws.label[(int64_t)f * (ws.P + 1) + pix + 1] - 1];
-        const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
-        if (off < 0) continue;
-        const int r = off + y - ws.bbox[((int64_t)f * ws.maxc + c) * 4 + 2];
-        if (left) atomicMin(ws.rowmin + (int64_t)f * ws.P + r, x);
-        if (right) atomicMax(ws.rowmax + (int64_t)f * ws.P + r, x);
+    PP_FOR_EACH_WORD(f, y, seg, wi) {
+        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
+        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
+        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
+        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        const int base = y * ws.w + seg * 64 + 1;
+        uint64_t m = ws.inbits[wi];
+        while (m) {
+            int i0, len;
+            const uint64_t run = first_run(m, &i0, &len);
+            m &= ~run;
+            const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
+            const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
+            if (off < 0) continue;
+            const int r = off + y - ws.bbox[((int64_t)f * ws.maxc + c) * 4 + 2];
+            atomicMin(ws.rowmin + (int64_t)f * ws.P + r, seg * 64 + i0);
+            atomicMax(ws.rowmax + (int64_t)f * ws.P + r, seg * 64 + i0 + len - 1);
+        }
     }
 }
 
@@ -662,10 +680,12 @@ int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_po
     const int64_t B = max_batch;
     int rc = 0;
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.label, B * (P + 1) * 4);
-    rc = rc ? rc : pp_alloc(pp, (void**)&ws.flags, B * P);
+    ws.wpr = (map_w + 63) / 64;
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.fgbits, B * map_h * ws.wpr * 8);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.inbits, B * map_h * ws.wpr * 8);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.compid, B * P * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.ncomp, B * 4);
-    rc = rc ? rc : pp_alloc(pp, (void**)&ws.slice_count, B * ((P + 63) / 64) * 4);
+    rc = rc ? rc : pp_alloc(pp, (void**)&ws.slice_count, B * map_h * ws.wpr * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.area2, B * ws.maxc * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.bbox, B * ws.maxc * 16);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowoff, B * ws.maxc * 4);
@@ -706,21 +726,19 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     ws.prob = prob_dev; ws.n = n; ws.thr = threshold;
     ws.orig_w = pp->orig_w_dev; ws.orig_h = pp->orig_h_dev;
     ws.out = out_dev; ws.out_count = counts_dev;
-    const int64_t total = (int64_t)n * ws.P;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    const int64_t waves = (int64_t)n * ((ws.P + 63) / 64);
-    const int wblocks = (int)std::min<int64_t>((waves + 3) / 4, 256 * 16);
-    const int iblocks = (int)std::min<int64_t>(((int64_t)n * ws.h * ((ws.w + 63) / 64) + 3) / 4, 256 * 16);
+    const int64_t words = (int64_t)n * ws.h * ws.wpr;
+    const int iblocks = (int)std::min<int64_t>((words + 3) / 4, 256 * 16);          // one wave per word
+    const int wblocks = (int)std::min<int64_t>((words + 255) / 256, 256 * 16);      // one thread per word
     hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_merge_fg_bg, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_classify, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_merge_inside, dim3(blocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_flatten_count, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_merge_fg_bg, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_classify, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_merge_inside, dim3(wblocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_count_roots, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_scan_slices, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     hipLaunchKernelGGL(pp_number_components, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
-    hipLaunchKernelGGL(pp_row_extents, dim3(blocks), dim3(256), 0, s, ws);
+    hipLaunchKernelGGL(pp_row_extents, dim3(wblocks), dim3(256), 0, s, ws);
     const size_t box_lds = (size_t)14 * ws.h * sizeof(int);
     const int use_lds = box_lds <= 60 * 1024;
     hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(BOX_THREADS), use_lds ? box_lds : 0, s, ws, use_lds);
