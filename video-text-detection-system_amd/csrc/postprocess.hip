@@ -47,7 +47,6 @@ struct PostWs {
     int maxcand;
     int* rowmin;       // [n][P]
     int* rowmax;       // [n][P]
-    int* hull;         // [n][P+8][12] scratch: chain stack, then hull points / calipers vect / inv_len
     vtd_detection* cand_rec;  // [n][maxcand]
     int* cand_valid;   // [n][maxcand]
     const int* orig_w; // [n]
@@ -401,27 +400,21 @@ __global__ void pp_row_extents(const PostWs ws) {
 
 struct fpt { float x, y; };
 
-// rotating calipers, minimum-area rectangle (float32, published operation order); out[6]
-__device__ void min_area_rect_dev(const fpt* points, int n, fpt* vect, float* inv_len, float* out) {
+// rotating calipers, minimum-area rectangle (float32, published operation order); out[6].  vect / inv_len are
+// precomputed by the whole workgroup; this part is the inherently sequential walk and runs on one lane out of LDS.
+__device__ void min_area_rect_dev(const fpt* points, int n, const fpt* vect, const float* inv_len, float* out) {
     float minarea = FLT_MAX;
-    int seq[4];
     int left = 0, bottom = 0, right = 0, top = 0;
     float orientation = 0, base_a, base_b = 0;
     float left_x, right_x, top_y, bottom_y;
-    fpt pt0 = points[0];
-    left_x = right_x = pt0.x;
-    top_y = bottom_y = pt0.y;
-    for (int i = 0; i < n; i++) {
+    left_x = right_x = points[0].x;
+    top_y = bottom_y = points[0].y;
+    for (int i = 1; i < n; i++) {
+        const fpt pt0 = points[i];
         if (pt0.x < left_x) { left_x = pt0.x; left = i; }
         if (pt0.x > right_x) { right_x = pt0.x; right = i; }
         if (pt0.y > top_y) { top_y = pt0.y; top = i; }
         if (pt0.y < bottom_y) { bottom_y = pt0.y; bottom = i; }
-        const fpt pt = points[(i + 1 < n) ? i + 1 : 0];
-        const double dx = (double)pt.x - (double)pt0.x, dy = (double)pt.y - (double)pt0.y;
-        vect[i].x = (float)dx;
-        vect[i].y = (float)dy;
-        inv_len[i] = (float)(1. / sqrt(dx * dx + dy * dy));
-        pt0 = pt;
     }
     {
         double ax = vect[n - 1].x, ay = vect[n - 1].y;
@@ -433,46 +426,46 @@ __device__ void min_area_rect_dev(const fpt* points, int n, fpt* vect, float* in
         }
     }
     base_a = orientation;
-    seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+    int s0 = bottom, s1 = right, s2 = top, s3 = left;  // calipers contact points (scalars: no private-array indexing)
     int best_left = 0, best_bottom = 0;
     float best_a = 0, best_b = 0, best_w = 0, best_h = 0;
     for (int k = 0; k < n; k++) {
-        float dp[4];
-        dp[0] = +base_a * vect[seq[0]].x + base_b * vect[seq[0]].y;
-        dp[1] = -base_b * vect[seq[1]].x + base_a * vect[seq[1]].y;
-        dp[2] = -base_a * vect[seq[2]].x - base_b * vect[seq[2]].y;
-        dp[3] = +base_b * vect[seq[3]].x - base_a * vect[seq[3]].y;
-        float maxcos = dp[0] * inv_len[seq[0]];
+        const fpt v0 = vect[s0], v1 = vect[s1], v2 = vect[s2], v3 = vect[s3];
+        const float dp0 = +base_a * v0.x + base_b * v0.y;
+        const float dp1 = -base_b * v1.x + base_a * v1.y;
+        const float dp2 = -base_a * v2.x - base_b * v2.y;
+        const float dp3 = +base_b * v3.x - base_a * v3.y;
+        float maxcos = dp0 * inv_len[s0];
         int main_element = 0;
-        for (int i = 1; i < 4; i++) {
-            const float cosalpha = dp[i] * inv_len[seq[i]];
-            if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; }
-        }
+        float cosalpha = dp1 * inv_len[s1];
+        if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
+        cosalpha = dp2 * inv_len[s2];
+        if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
+        cosalpha = dp3 * inv_len[s3];
+        if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
         {
-            const int pindex = seq[main_element];
+            const int pindex = main_element == 0 ? s0 : main_element == 1 ? s1 : main_element == 2 ? s2 : s3;
             const float lead_x = vect[pindex].x * inv_len[pindex];
             const float lead_y = vect[pindex].y * inv_len[pindex];
             switch (main_element) {
-                case 0: base_a = lead_x; base_b = lead_y; break;
-                case 1: base_a = lead_y; base_b = -lead_x; break;
-                case 2: base_a = -lead_x; base_b = -lead_y; break;
-                default: base_a = -lead_y; base_b = lead_x; break;
+                case 0: base_a = lead_x; base_b = lead_y; s0 = s0 + 1 == n ? 0 : s0 + 1; break;
+                case 1: base_a = lead_y; base_b = -lead_x; s1 = s1 + 1 == n ? 0 : s1 + 1; break;
+                case 2: base_a = -lead_x; base_b = -lead_y; s2 = s2 + 1 == n ? 0 : s2 + 1; break;
+                default: base_a = -lead_y; base_b = lead_x; s3 = s3 + 1 == n ? 0 : s3 + 1; break;
             }
         }
-        seq[main_element] += 1;
-        seq[main_element] = (seq[main_element] == n) ? 0 : seq[main_element];
         {
-            float dx = points[seq[1]].x - points[seq[3]].x;
-            float dy = points[seq[1]].y - points[seq[3]].y;
+            float dx = points[s1].x - points[s3].x;
+            float dy = points[s1].y - points[s3].y;
             const float width = dx * base_a + dy * base_b;
-            dx = points[seq[2]].x - points[seq[0]].x;
-            dy = points[seq[2]].y - points[seq[0]].y;
+            dx = points[s2].x - points[s0].x;
+            dy = points[s2].y - points[s0].y;
             const float height = -dx * base_b + dy * base_a;
             const float area = width * height;
             if (area <= minarea) {
                 minarea = area;
-                best_left = seq[3]; best_a = base_a; best_w = width;
-                best_b = base_b; best_h = height; best_bottom = seq[0];
+                best_left = s3; best_a = base_a; best_w = width;
+                best_b = base_b; best_h = height; best_bottom = s0;
             }
         }
     }
@@ -489,62 +482,88 @@ __device__ void min_area_rect_dev(const fpt* points, int n, fpt* vect, float* in
     }
 }
 
-__device__ __forceinline__ long long cross3(int ox, int oy, int ax, int ay, int bx, int by) {
-    return (long long)(ax - ox) * (by - oy) - (long long)(ay - oy) * (bx - ox);
-}
-
-// one 256-thread workgroup per candidate: the row table is staged into LDS, thread 0 runs the (inherently
-// sequential) monotone chains + rotating calipers out of LDS, then all threads average the probability slice.
+// One 256-thread workgroup per candidate.
+//   1. the candidate's row table (min / max x per row) is staged into LDS
+//   2. hull membership is decided for every row in parallel: row r's right end is a vertex of the clockwise hull iff
+//      min_{i<r} slope(i,r) > max_{j>r} slope(r,j) (x as a function of the row, exact integer fraction compares), its
+//      left end iff max_{i<r} slope < min_{j>r} slope -- the same strict hull the sequential monotone chain builds
+//   3. one lane compacts the vertices into the published order (clockwise on screen, ending at the raster-first pixel),
+//      all lanes compute the edge vectors / inverse lengths, one lane walks the calipers
+//   4. all lanes average the probability slice of the resulting box
 constexpr int BOX_THREADS = 256;
-__global__ __launch_bounds__(BOX_THREADS) void pp_boxes(const PostWs ws, const int use_lds) {
-    extern __shared__ __attribute__((aligned(16))) int box_lds[];  // [2h] row table + [12h] hull scratch when use_lds
+__device__ __forceinline__ bool frac_lt(int an, int ad, int bn, int bd) { return (long long)an * bd < (long long)bn * ad; }  // an/ad < bn/bd, ad,bd > 0
+
+__global__ __launch_bounds__(BOX_THREADS) void pp_boxes(const PostWs ws) {
+    extern __shared__ __attribute__((aligned(16))) int box_lds[];
     const int f = blockIdx.y;
     __shared__ int sh_i[8];
     __shared__ double sh_acc[BOX_THREADS / 64];
+    const int hcap = ws.h;
+    int* rmin = box_lds;                       // [h]
+    int* rmax = box_lds + hcap;                // [h]
+    int* isv = box_lds + 2 * hcap;             // [h] bit0: right end is a hull vertex, bit1: left end is
+    fpt* pts = (fpt*)(box_lds + 3 * hcap);     // [2h+2]
+    fpt* vect = pts + 2 * hcap + 2;            // [2h+2]
+    float* inv_len = (float*)(vect + 2 * hcap + 2);  // [2h+2]
   for (int k = blockIdx.x; k < ws.ncand[f]; k += gridDim.x) {
     __syncthreads();
     const int c = ws.candlist[(int64_t)f * ws.maxcand + k];
     const int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
     const int ytop = bb[2], H = bb[3] - bb[2] + 1;
     const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
-    const int* rmin = ws.rowmin + (int64_t)f * ws.P + off;
-    const int* rmax = ws.rowmax + (int64_t)f * ws.P + off;
-    int* st = ws.hull + ((int64_t)f * (ws.P + 8) + off) * 12;
-    if (use_lds) {
-        for (int r = threadIdx.x; r < H; r += BOX_THREADS) { box_lds[r] = rmin[r]; box_lds[ws.h + r] = rmax[r]; }
-        rmin = box_lds; rmax = box_lds + ws.h; st = box_lds + 2 * ws.h;
-        __syncthreads();
+    for (int r = threadIdx.x; r < H; r += BOX_THREADS) {
+        rmin[r] = ws.rowmin[(int64_t)f * ws.P + off + r];
+        rmax[r] = ws.rowmax[(int64_t)f * ws.P + off + r];
     }
+    __syncthreads();
+    for (int r = threadIdx.x; r < H; r += BOX_THREADS) {
+        int flag = 0;
+        if (r == 0 || r == H - 1) {
+            flag = 3;
+        } else {
+            // right ends: concave envelope of rmax(row)
+            int mn_n = rmax[r] - rmax[0], mn_d = r;             // min over i<r of (x_r - x_i)/(r - i)
+            int mnL_n = rmin[r] - rmin[0], mnL_d = r;           // max over i<r for the left ends
+            for (int i = 1; i < r; ++i) {
+                const int n1 = rmax[r] - rmax[i], n2 = rmin[r] - rmin[i], d = r - i;
+                if (frac_lt(n1, d, mn_n, mn_d)) { mn_n = n1; mn_d = d; }
+                if (frac_lt(mnL_n, mnL_d, n2, d)) { mnL_n = n2; mnL_d = d; }
+            }
+            int mx_n = rmax[r + 1] - rmax[r], mx_d = 1;         // max over j>r of (x_j - x_r)/(j - r)
+            int mxL_n = rmin[r + 1] - rmin[r], mxL_d = 1;       // min over j>r for the left ends
+            for (int j = r + 2; j < H; ++j) {
+                const int n1 = rmax[j] - rmax[r], n2 = rmin[j] - rmin[r], d = j - r;
+                if (frac_lt(mx_n, mx_d, n1, d)) { mx_n = n1; mx_d = d; }
+                if (frac_lt(n2, d, mxL_n, mxL_d)) { mxL_n = n2; mxL_d = d; }
+            }
+            if (frac_lt(mx_n, mx_d, mn_n, mn_d)) flag |= 1;     // strictly convex turn on the right chain
+            if (frac_lt(mnL_n, mnL_d, mxL_n, mxL_d)) flag |= 2; // and on the left chain
+        }
+        isv[r] = flag;
+    }
+    __syncthreads();
     vtd_detection rec;
     if (threadIdx.x == 0) {
-        // scratch `st`: 12 words per table row of this candidate.  The chain stack holds <= 2H+1 points; the strict
-        // hull has n <= 2H vertices and is converted to float in place, followed by vect[n] and inv_len[n]: 5n <= 10H.
-        int m = 0;
-        auto push_chain = [&](int base, int px, int py) {
-            while (m - base >= 2 && cross3(st[2 * (m - 2)], st[2 * (m - 2) + 1], st[2 * (m - 1)], st[2 * (m - 1) + 1], px, py) <= 0) m--;
-            st[2 * m] = px; st[2 * m + 1] = py; m++;
-        };
-        // chain 1: raster-first pixel, then the right ends of the rows going down
-        push_chain(0, rmin[0], ytop);
-        for (int r = 0; r < H; ++r) {
-            if (r == 0 && rmax[0] == rmin[0]) continue;
-            push_chain(0, rmax[r], ytop + r);
-        }
-        // chain 2: from the raster-last pixel up the left ends
-        const int base2 = m - 1;
-        for (int r = H - 1; r >= 0; --r) {
-            if (r == H - 1 && rmin[r] == rmax[r]) continue;
-            push_chain(base2, rmin[r], ytop + r);
-        }
-        // st[0] and st[m-1] are both the raster-first pixel: hull = st[1..m-1], clockwise on screen, ending there
-        const int n = m - 1;
-        fpt* pts = (fpt*)st;
-        fpt* vect = pts + n;
-        float* inv_len = (float*)(vect + n);
-        for (int i = 0; i < n; ++i) {  // in place, reading one point ahead of the write position
-            const int px = st[2 * (i + 1)], py = st[2 * (i + 1) + 1];
-            pts[i].x = (float)px; pts[i].y = (float)py;
-        }
+        // clockwise on screen starting just after the raster-first pixel S = (rmin[0], ytop) and ending at S:
+        // right ends going down, then left ends going up (corners shared by both chains are emitted once)
+        int n = 0;
+        for (int r = 0; r < H; ++r)
+            if ((isv[r] & 1) && !(r == 0 && rmax[0] == rmin[0])) { pts[n].x = (float)rmax[r]; pts[n].y = (float)(ytop + r); ++n; }
+        for (int r = H - 1; r >= 0; --r)
+            if ((isv[r] & 2) && !(r == H - 1 && rmin[r] == rmax[r])) { pts[n].x = (float)rmin[r]; pts[n].y = (float)(ytop + r); ++n; }
+        sh_i[5] = n;
+    }
+    __syncthreads();
+    const int n = sh_i[5];
+    for (int i = threadIdx.x; i < n; i += BOX_THREADS) {
+        const fpt p0 = pts[i], p1 = pts[i + 1 < n ? i + 1 : 0];
+        const double dx = (double)p1.x - (double)p0.x, dy = (double)p1.y - (double)p0.y;
+        vect[i].x = (float)dx;
+        vect[i].y = (float)dy;
+        inv_len[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         float cx = 0, cy = 0, bw = 0, bh = 0, angle = 0;
         if (n > 2) {
             float o[6];
@@ -604,14 +623,11 @@ __global__ __launch_bounds__(BOX_THREADS) void pp_boxes(const PostWs ws, const i
         continue;
     }
     const int sy0 = sh_i[1], sy1 = sh_i[2], sx0 = sh_i[3], sx1 = sh_i[4];
-    const int sw = max(sx1 - sx0, 0), shh = max(sy1 - sy0, 0);
-    const int64_t cnt = (int64_t)sw * shh;
+    const int64_t cnt = (int64_t)max(sx1 - sx0, 0) * max(sy1 - sy0, 0);
     double acc = 0.0;
     const float* P = ws.prob + (int64_t)f * ws.P;
-    for (int64_t t = threadIdx.x; t < cnt; t += BOX_THREADS) {
-        const int yy = sy0 + (int)(t / sw), xx = sx0 + (int)(t % sw);
-        acc += (double)P[(int64_t)yy * ws.w + xx];
-    }
+    for (int yy = sy0 + (threadIdx.x >> 5); yy < sy1; yy += BOX_THREADS / 32)   // 8 rows x 32 columns per pass
+        for (int xx = sx0 + (threadIdx.x & 31); xx < sx1; xx += 32) acc += (double)P[(int64_t)yy * ws.w + xx];
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if ((threadIdx.x & 63) == 0) sh_acc[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -669,6 +685,7 @@ extern "C" {
 
 int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_postproc** out) {
     if (!out || max_batch <= 0 || map_h <= 0 || map_w <= 0 || max_out <= 0 || (int64_t)map_h * map_w > (1 << 26)) return -1100;
+    if (map_h > 2900 || map_w >= 32768) return -1100;  // the per-candidate hull workspace lives in LDS; coordinates must keep fraction compares in range
     auto* pp = new vtd_postproc();
     pp->max_batch = max_batch; pp->h = map_h; pp->w = map_w; pp->max_out = max_out;
     PostWs& ws = pp->ws;
@@ -693,7 +710,6 @@ int vtd_postproc_create(int max_batch, int map_h, int map_w, int max_out, vtd_po
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.ncand, B * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowmin, B * P * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.rowmax, B * P * 4);
-    rc = rc ? rc : pp_alloc(pp, (void**)&ws.hull, B * (P + 8) * 48);
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.cand_rec, B * ws.maxcand * sizeof(vtd_detection));
     rc = rc ? rc : pp_alloc(pp, (void**)&ws.cand_valid, B * ws.maxcand * 4);
     rc = rc ? rc : pp_alloc(pp, (void**)&pp->orig_w_dev, B * 4);
@@ -739,9 +755,14 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     hipLaunchKernelGGL(pp_row_extents, dim3(wblocks), dim3(256), 0, s, ws);
-    const size_t box_lds = (size_t)14 * ws.h * sizeof(int);
-    const int use_lds = box_lds <= 60 * 1024;
-    hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(BOX_THREADS), use_lds ? box_lds : 0, s, ws, use_lds);
+    const size_t box_lds = ((size_t)3 * ws.h + (size_t)5 * (2 * ws.h + 2)) * sizeof(int);  // row table, flags, hull points, vect, inv_len
+    if (box_lds > 150 * 1024) return -1011;
+    static bool box_attr = false;
+    if (!box_attr) {
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)pp_boxes, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        box_attr = true;
+    }
+    hipLaunchKernelGGL(pp_boxes, dim3(std::min(ws.maxcand, 128), n), dim3(BOX_THREADS), box_lds, s, ws);
     hipLaunchKernelGGL(pp_emit, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     return -(int)hipGetLastError();
 }
