@@ -58,11 +58,17 @@ struct PostWs {
 
 __device__ __forceinline__ int ld_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ int uf_find(const int* L, int a) {
+// find with path halving.  Vertical structures (the background strip beside a text box, a tall stroke) are joined row
+// by row and would otherwise leave parent chains as long as the structure is tall for every later lookup.  A halving
+// store only ever replaces a non-root's parent by one of its ancestors (same set, smaller index), so it is safe next to
+// concurrent atomicMin unions: a link it overwrites was already re-united by the thread that lost it.
+__device__ __forceinline__ int uf_find(int* L, int a) {
     int p = ld_relaxed(L + a);
     while (p != a) {
+        const int gp = ld_relaxed(L + p);
+        if (gp != p) __hip_atomic_store(L + a, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a = p;
-        p = ld_relaxed(L + a);
+        p = gp;
     }
     return a;
 }
@@ -109,38 +115,41 @@ __device__ __forceinline__ uint64_t first_run(uint64_t m, int* i0, int* len) {
     return (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << i;
 }
 
-// ---- stage 1: threshold + horizontal runs.  One wave owns one word: a ballot of the foreground bit is the packed word
-// and gives every lane the start of its same-class run inside the word, which becomes its initial union-find parent.
-// Horizontal connectivity therefore costs no atomics at all, and the (usually huge) frame background collapses to one
-// run per word instead of one node per pixel.
+// ---- stage 1: threshold + horizontal runs.  One wave owns one row and walks its words: a ballot of the foreground bit
+// is the packed word and gives every lane the start of its same-class run, carried across word seams, which becomes its
+// initial union-find parent.  Horizontal connectivity therefore costs no atomics at all, and the (usually huge) frame
+// background collapses to one run per row instead of one node per pixel.
 __global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
     const int lane = threadIdx.x & 63;
-    const int64_t total = (int64_t)ws.n * ws.h * ws.wpr;
+    const int64_t total = (int64_t)ws.n * ws.h;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t wi = wave0; wi < total; wi += nwaves) {
-        const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
-        const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
-        const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const int x = seg * 64 + lane;
-        const bool valid = x < ws.w;
-        const int pix = y * ws.w + x;
-        const bool fg = valid && (ws.prob[(int64_t)f * ws.P + pix] > ws.thr);
-        const unsigned long long m = __ballot(fg);
-        const unsigned long long same = fg ? m : ~m;
-        const unsigned long long below = lane ? (~same & ((1ull << lane) - 1ull)) : 0ull;
-        const int start = below ? 64 - __clzll((long long)below) : 0;
-        if (valid) {
-            int* L = ws.label + (int64_t)f * (ws.P + 1);
-            int parent = y * ws.w + seg * 64 + start + 1;
-            // background on the frame's border belongs to the (virtual) outside: hang it on the sentinel
-            if (!fg && (y == 0 || y == ws.h - 1 || x == 0)) parent = 0;
-            L[pix + 1] = parent;
+    for (int64_t ri = wave0; ri < total; ri += nwaves) {
+        const int f = (int)(ri / ws.h), y = (int)(ri - (int64_t)f * ws.h);
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
+        int carry_start = 0;      // x of the start of the run that reaches the previous word's last pixel
+        bool carry_fg = false;
+        for (int seg = 0; seg < ws.wpr; ++seg) {
+            const int x = seg * 64 + lane;
+            const bool valid = x < ws.w;
+            const int pix = y * ws.w + x;
+            const bool fg = valid && (ws.prob[(int64_t)f * ws.P + pix] > ws.thr);
+            const unsigned long long m = __ballot(fg);
+            const unsigned long long same = fg ? m : ~m;
+            const unsigned long long below = lane ? (~same & ((1ull << lane) - 1ull)) : 0ull;
+            int start = below ? seg * 64 + 64 - __clzll((long long)below) : seg * 64;
+            if (!below && seg > 0 && fg == carry_fg) start = carry_start;  // the run continues from the previous word
+            if (valid) {
+                int parent = y * ws.w + start + 1;
+                // background on the frame's border belongs to the (virtual) outside: hang it on the sentinel
+                if (!fg && (y == 0 || y == ws.h - 1 || x == 0)) parent = 0;
+                L[pix + 1] = parent;
+            }
+            carry_start = __shfl(start, 63);
+            carry_fg = (m >> 63) & 1;
+            if (lane == 0) ws.fgbits[((int64_t)f * ws.h + y) * ws.wpr + seg] = m;
         }
-        if (lane == 0) {
-            ws.fgbits[wi] = m;
-            if (rem == 0) ws.label[(int64_t)f * (ws.P + 1)] = 0;
-        }
+        if (y == 0 && lane == 0) L[0] = 0;
     }
 }
 
@@ -159,7 +168,6 @@ __global__ void pp_merge_fg_bg(const PostWs ws) {
         const uint64_t vm = valid_mask(seg, ws.w, ws.wpr);
         const Words3 cur = load3(B, y, seg, ws.h, ws.wpr), up = load3(B, y - 1, seg, ws.h, ws.wpr);
         const int base = y * ws.w + seg * 64 + 1;  // label index of bit 0
-        if (seg > 0 && (int)(cur.c & 1) == (int)(cur.l >> 63)) uf_unite(L, base, base - 1);  // run continues across the word seam
         if (seg == ws.wpr - 1 && !((cur.c >> ((ws.w - 1) & 63)) & 1)) uf_unite(L, base + ((ws.w - 1) & 63), 0);  // background at the right frame edge
         if (y == 0) continue;
         const uint64_t W = west(cur), E = east(cur), N = up.c, NW = west(up), NE = east(up);
@@ -184,7 +192,7 @@ __global__ void pp_classify(const PostWs ws) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
         const uint64_t cur = ws.fgbits[wi];
         uint64_t bg = ~cur & valid_mask(seg, ws.w, ws.wpr), holes = 0;
         const int base = y * ws.w + seg * 64 + 1;
@@ -320,7 +328,7 @@ __global__ void pp_stats(const PostWs ws) {
         const Words3 a = load3(I, y, seg, ws.h, ws.wpr);
         if (!a.c) continue;
         const Words3 b = load3(I, y + 1, seg, ws.h, ws.wpr);
-        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
         const uint64_t a1 = east(a), b1 = east(b);
         const uint64_t four = a.c & a1 & b.c & b1;
         const uint64_t three = (a.c & a1 & b.c & ~b1) | (a.c & a1 & ~b.c & b1) | (a.c & ~a1 & b.c & b1) | (~a.c & a1 & b.c & b1);
@@ -381,7 +389,7 @@ __global__ void pp_row_extents(const PostWs ws) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const int* L = ws.label + (int64_t)f * (ws.P + 1);
+        int* L = ws.label + (int64_t)f * (ws.P + 1);
         const int base = y * ws.w + seg * 64 + 1;
         uint64_t m = ws.inbits[wi];
         while (m) {
@@ -743,7 +751,7 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     ws.orig_w = pp->orig_w_dev; ws.orig_h = pp->orig_h_dev;
     ws.out = out_dev; ws.out_count = counts_dev;
     const int64_t words = (int64_t)n * ws.h * ws.wpr;
-    const int iblocks = (int)std::min<int64_t>((words + 3) / 4, 256 * 16);          // one wave per word
+    const int iblocks = (int)std::min<int64_t>(((int64_t)n * ws.h + 3) / 4, 256 * 16);  // one wave per row
     const int wblocks = (int)std::min<int64_t>((words + 255) / 256, 256 * 16);      // one thread per word
     hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(pp_merge_fg_bg, dim3(wblocks), dim3(256), 0, s, ws);
