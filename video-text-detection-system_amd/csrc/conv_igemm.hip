@@ -30,6 +30,22 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+// scheduling pins for one half K-step: NLOAD LDS-DMA instructions spread evenly between NM MFMAs
+template <int NM, int NLOAD, int K = 0, int PREV = 0>
+__device__ __forceinline__ void pin_loads_between_mfmas() {
+    if constexpr (K < NLOAD) {
+        constexpr int AT = (K + 1) * NM / (NLOAD + 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, AT - PREV, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);          // VMEM (the LDS-DMA)
+        pin_loads_between_mfmas<NM, NLOAD, K + 1, AT>();
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - PREV, 0);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
     constexpr int NW = WM * WN;
@@ -93,23 +109,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // K walk state (scalar): kb = element offset of the current K-step from the tap-(0,0) pixel
     int kb = 0, t_c = 0, t_s = 0;
     int w_cin = p.cin_steps, w_kw = p.kw, w_s = p.s_step, w_r = p.r_step;
-    auto stage = [&](int ks, int buf) {
+    bool second = false;  // classed mode: walking the second source
+    // One LDS-DMA instruction (1 KB) of K-step `ks` into buffer `buf`: j < A_INST feeds the A tile, the rest the B tile.
+    auto issue_load = [&](int j, int ks, int buf) {
         char* abase = smem + buf * STAGE;
-        char* bbase = abase + A_BYTES;
-        const bool second = CLASSED && ks >= p.seg1_steps;  // wave-uniform
+        if (j < A_INST) {
+            const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + kb;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (j * NW + w) * 1024), 16, 0, 0);
+        } else {
+            const int i = j - A_INST;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64), (VTD_AS3 void*)(abase + A_BYTES + (i * NW + w) * 1024), 16, 0, 0);
+        }
+    };
+    auto begin_step = [&](int ks) {  // before the first load of K-step ks
         if (CLASSED && ks == p.seg1_steps) {  // switch the walk to the second source's 3x3 window
-            kb = 0; t_c = 0; t_s = 0;
+            kb = 0; t_c = 0; t_s = 0; second = true;
             w_cin = p.cin_steps2; w_kw = p.kw2; w_s = p.s_step2; w_r = p.r_step2;
         }
-#pragma unroll
-        for (int i = 0; i < A_INST; ++i) {
-            const half_t* src = (second ? aptr2[CLASSED ? i : 0] : aptr[i]) + kb;
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (i * NW + w) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_INST; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64), (VTD_AS3 void*)(bbase + (i * NW + w) * 1024), 16, 0, 0);
-        // advance to the next K-step (stages are always issued in K order)
+    };
+    auto end_step = [&]() {  // after the last load of a K-step: advance the walk (steps are always issued in K order)
         kb += 64;
         if (++t_c == w_cin) {
             t_c = 0;
@@ -119,6 +137,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
                 kb += w_r - w_kw * w_s;
             }
         }
+    };
+    auto stage = [&](int ks, int buf) {
+        begin_step(ks);
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) issue_load(j, ks, buf);
+        end_step();
     };
 
     // ---- compute state
@@ -134,39 +158,73 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // One half K-step (32 deep) of MFMAs out of buffer `sb`; when LOADING, `nload` LDS-DMA instructions [j0, j0+nload) of
+    // K-step `lks` are issued BETWEEN the MFMAs: a global_load_lds costs the wave ~60-100 issue cycles, which hide
+    // behind the matrix pipe only if they are spread over it (back to back at the top of the step they cost as much
+    // as the step's MFMAs).  sched_group_barrier pins the interleave the source order asks for.
+    auto half_step = [&](const char* sb, int kk, auto nload_c, int lks, int lbuf, int j0) {
+        constexpr int nload = decltype(nload_c)::value;
+        const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
+        half8 af[FM], bf[FN];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + phys);
+        constexpr int NM = FM * FN;
+        int q = 0, issued = 0;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
+                ++q;
+                // spread the loads evenly: the k-th load goes after MFMA number (k+1)*NM/(nload+1)
+                if (issued < nload && q >= (issued + 1) * NM / (nload + 1)) {
+                    issue_load(j0 + issued, lks, lbuf);
+                    ++issued;
+                }
+            }
+        // pin that order: fragment reads first, then MFMA groups with one LDS-DMA after each
+        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // DS read
+        pin_loads_between_mfmas<NM, nload>();
+    };
+
     const int nk = p.K >> 6;
     stage(0, 0);
     if (STAGES == 3 && nk > 1) stage(1, 1);
 
     int buf = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        // the loads of K-step ks have landed once at most the youngest prefetched step is still outstanding
-        if (STAGES == 3 && ks + 1 < nk) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
+    constexpr int L0 = (LOADS + 1) / 2, L1 = LOADS - L0;
+    const int nmain = nk - (STAGES - 1) > 0 ? nk - (STAGES - 1) : 0;
+    // steady state: K-step ks is consumed while K-step ks + STAGES - 1 is fetched
+    for (int ks = 0; ks < nmain; ++ks) {
+        if (STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // everyone's loads landed; everyone finished reading the buffer refilled below
-        {
-            const int ahead = ks + STAGES - 1;
-            if (ahead < nk) {
-                int nb = buf + STAGES - 1;
-                nb = nb >= STAGES ? nb - STAGES : nb;
-                stage(ahead, nb);
-            }
-        }
+        int nb = buf + STAGES - 1;
+        nb = nb >= STAGES ? nb - STAGES : nb;
+        const int lks = ks + STAGES - 1;
         const char* sb = smem + buf * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
-            half8 af[FM], bf[FN];
-#pragma unroll
-            for (int j = 0; j < FM; ++j) af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
-#pragma unroll
-            for (int i = 0; i < FN; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + phys);
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
+        if constexpr (STAGES == 3) {
+            // two K-steps of slack: spread the LDS-DMA issue over the whole step's MFMAs
+            begin_step(lks);
+            half_step(sb, 0, IntC<L0>{}, lks, nb, 0);
+            half_step(sb, 1, IntC<L1>{}, lks, nb, L0);
+            end_step();
+        } else {
+            // one K-step of slack only: the loads must leave first (another workgroup on the CU covers their issue time)
+            stage(lks, nb);
+            half_step(sb, 0, IntC<0>{}, 0, 0, 0);
+            half_step(sb, 1, IntC<0>{}, 0, 0, 0);
         }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+    // drain: the last STAGES-1 K-steps have nothing left to prefetch
+    for (int ks = nmain; ks < nk; ++ks) {
+        if (STAGES == 3 && ks + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + buf * STAGE;
+        half_step(sb, 0, IntC<0>{}, 0, 0, 0);
+        half_step(sb, 1, IntC<0>{}, 0, 0, 0);
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
 
