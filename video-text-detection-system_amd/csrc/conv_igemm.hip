@@ -83,7 +83,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const half_t* aptr2[CLASSED ? A_INST : 1];
     // classed mode: a tile is BM entries of the per-image pixel list and carries its own weight class
     const int cl_img = CLASSED ? tm / p.tiles_per_img : 0;
-    const int cl_lt = CLASSED ? tm - cl_img * p.tiles_per_img : 0;
+    const int cl_entry = CLASSED ? p.tile_combo[tm - cl_img * p.tiles_per_img] : 0;  // weight class | pixel-list chunk << 8
+    const int cl_lt = cl_entry >> 8;
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
         if constexpr (CLASSED) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         }
     }
     const half_t* wbase = p.wgt;
-    if constexpr (CLASSED) wbase += (int64_t)p.tile_combo[cl_lt] * p.cout_pad * p.K;
+    if constexpr (CLASSED) wbase += (int64_t)(cl_entry & 0xff) * p.cout_pad * p.K;
     const half_t* bptr[B_INST];
 #pragma unroll
     for (int i = 0; i < B_INST; ++i) bptr[i] = wbase + (int64_t)(n0 + (i * NW + w) * 8 + lrow) * p.K + c_log * 8;

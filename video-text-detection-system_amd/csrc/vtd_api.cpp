@@ -556,7 +556,10 @@ static int compose_head_entry(const ModelBase* d, const std::string& hp, int c2c
     return 0;
 }
 
-// per-image pixel list for the classed op: 16 (row kind x column kind) groups, each padded to whole 128-row tiles
+// per-image pixel list for the classed op: 16 (row kind x column kind) groups, each padded to whole 128-row tiles.
+// `tile_combo` then lists the tiles in EXECUTION order as (weight class | pixel-list chunk << 8): the four parity classes
+// of the image interior are interleaved chunk by chunk, so the tiles that gather the same rows of C2 / L3 run back to
+// back on one XCD and its L2 serves the 4x overlap (class-major order re-streamed the whole image once per class).
 static void build_pixel_list(int h, int w, std::vector<uint32_t>& plist, std::vector<int>& tile_combo) {
     auto kind_values = [](int n, int kind) {
         std::vector<int> v;
@@ -567,15 +570,29 @@ static void build_pixel_list(int h, int w, std::vector<uint32_t>& plist, std::ve
     };
     plist.clear();
     tile_combo.clear();
+    std::vector<std::vector<int>> chunks(16);  // per combo: its pixel-list chunk indices, in raster order
     for (int yk = 0; yk < 4; ++yk)
         for (int xk = 0; xk < 4; ++xk) {
             const std::vector<int> ys = kind_values(h, yk), xs = kind_values(w, xk);
             size_t cnt = 0;
+            const size_t first_chunk = plist.size() / 128;
             for (int y : ys)
                 for (int x : xs) { plist.push_back((uint32_t)y | ((uint32_t)x << 16)); ++cnt; }
             while (cnt % 128) { plist.push_back(0xffffffffu); ++cnt; }
-            for (size_t t = 0; t < cnt / 128; ++t) tile_combo.push_back(yk * 4 + xk);
+            for (size_t t = 0; t < cnt / 128; ++t) chunks[yk * 4 + xk].push_back((int)(first_chunk + t));
         }
+    const int interior[4] = {1 * 4 + 1, 1 * 4 + 2, 2 * 4 + 1, 2 * 4 + 2};  // (mid even|odd rows) x (mid even|odd columns)
+    size_t longest = 0;
+    for (int c : interior) longest = std::max(longest, chunks[c].size());
+    for (size_t t = 0; t < longest; ++t)
+        for (int c : interior)
+            if (t < chunks[c].size()) tile_combo.push_back(c | (chunks[c][t] << 8));
+    for (int c = 0; c < 16; ++c) {
+        bool is_interior = false;
+        for (int q : interior) is_interior |= q == c;
+        if (!is_interior)
+            for (int ch : chunks[c]) tile_combo.push_back(c | (ch << 8));
+    }
 }
 
 static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDesc& c2, const TensorDesc& l3, TensorDesc& out,

@@ -62,7 +62,7 @@ struct ConvParams {
     int ldc;               // EPI_OUT_F32 row stride
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
-    const int* tile_combo;   // per local tile: weight class (selects a [cout_pad][K] block of wgt)
+    const int* tile_combo;   // per tile in execution order: weight class | pixel-list chunk << 8
     int tiles_per_img;
     const half_t* in2;       // second source (L3): gathered at (y>>1, x>>1) - 1
     int in2_hp, in2_wp, in2_c, in2_ring;
