@@ -59,7 +59,9 @@ void vtd_detector_destroy(vtd_detector* d);
 int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_data, int64_t numel);
 /* Build options, before finalize.  "fuse_fpn_head" (default 1): evaluate FPN lateral(C2) + top-down add + P2 smooth +
  * head conv as one algebraically composed convolution (the 256-channel P2 map is never formed; its "p2" tap is then
- * unavailable).  0 keeps the layer-by-layer graph. */
+ * unavailable).  0 keeps the layer-by-layer graph.
+ * "fuse_stem_pool" (default 1): backbone conv1 7x7/s2 + bn1 + relu + maxpool 3x3/s2 run as one kernel that only writes the
+ * pooled map (tap "pool"); 0 runs the generic convolution + a separate pool kernel and exposes the tap "stem". */
 int vtd_detector_set_option(vtd_detector* d, const char* name, int value);
 /* Folds BatchNorm, repacks to the kernels' fp16 layouts and uploads.  Fails (-1103) if a key is missing. */
 int vtd_detector_finalize(vtd_detector* d, vtd_stream stream);

@@ -21,7 +21,7 @@ def _rel(a, b):
 def r18(hip):
     from vtd_amd.engine import DetectorEngine
     sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
-    eng = DetectorEngine("resnet18", sd, max_batch=4, options={"fuse_fpn_head": 0})  # layer-by-layer graph: every tap exists
+    eng = DetectorEngine("resnet18", sd, max_batch=4, options={"fuse_fpn_head": 0, "fuse_stem_pool": 0})  # layer-by-layer graph: every tap exists
     yield eng, sd
     eng.close()
 
@@ -60,7 +60,8 @@ def test_dbnet_r18_taps_and_probability(r18):
     torch.cuda.synchronize()
     ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
     stem_ref = torch.relu(onets._bn(torch.nn.functional.conv2d(x, sd["backbone.0.weight"], None, 2, 3), sd, "backbone.1"))
-    errs = {"stem": _rel(eng.read_tap("stem", 2), stem_ref.numpy())}
+    pool_ref = torch.nn.functional.max_pool2d(stem_ref, 3, 2, 1)
+    errs = {"stem": _rel(eng.read_tap("stem", 2), stem_ref.numpy()), "pool": _rel(eng.read_tap("pool", 2), pool_ref.numpy())}
     for i, name in enumerate(("c2", "c3", "c4", "c5")):
         errs[name] = _rel(eng.read_tap(name, 2), ref["taps"][i].numpy())
     errs["p2"] = _rel(eng.read_tap("p2", 2), ref["p2"].numpy())
@@ -101,6 +102,31 @@ def test_dbnet_fused_fpn_head_entry(r18, r18_fused):
     ref_t = onets.dbnet_forward(x[:1], sd, "resnet18", want_threshold=True)["threshold"]
     assert float((pf["threshold"][:1].cpu() - ref_t).abs().max()) <= 2e-3
     assert eng_f.macs_per_frame == eng_u.macs_per_frame  # algorithmic count does not depend on the fusion
+
+
+def test_dbnet_fused_stem_pool(r18, r18_fused):
+    """conv1 7x7/s2 + bn1 + relu + maxpool in one kernel (tile = 7x8 pooled pixels, halo recomputed): the pooled map must
+    match the fp32 oracle everywhere, including the image border (pool padding) and the partial last tile row, and agree
+    with the two-kernel path to fp16 rounding."""
+    eng_u, sd = r18
+    eng_f, _ = r18_fused
+    x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(13))
+    x[2] = x[2].abs() * 3  # a frame with large positive activations everywhere
+    stem_ref = torch.relu(onets._bn(torch.nn.functional.conv2d(x, sd["backbone.0.weight"], None, 2, 3), sd, "backbone.1"))
+    pool_ref = torch.nn.functional.max_pool2d(stem_ref, 3, 2, 1).numpy()
+    eng_f.forward(x)
+    got_f = eng_f.read_tap("pool", 3)
+    eng_u.forward(x)
+    got_u = eng_u.read_tap("pool", 3)
+    assert got_f.shape == pool_ref.shape == (3, 64, 160, 160)
+    scale = np.abs(pool_ref).max()
+    err = np.abs(got_f - pool_ref) / scale
+    print("fused stem+pool rel err", err.max(), "border", err[:, :, [0, 159], :].max(), err[:, :, :, [0, 159]].max(),
+          "vs two-kernel path", np.abs(got_f - got_u).max() / scale)
+    assert err.max() < 5e-3
+    assert np.abs(got_f - got_u).max() / scale < 2e-3
+    with pytest.raises(Exception):
+        eng_f.read_tap("stem", 1)  # never materialised
 
 
 def test_dbnet_batch_independence_and_threshold_branch(r18):

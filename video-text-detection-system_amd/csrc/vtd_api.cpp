@@ -23,6 +23,8 @@ int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* ou
 int vtd_launch_nchw_to_input(const float* x, half_t* out, int n, hipStream_t stream);
 int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int kh, int kw, int sh, int sw, int pad_h, int pad_w,
                        hipStream_t stream);
+void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
+int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
 
 int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
@@ -100,13 +102,15 @@ struct ConvOp {
 };
 
 struct Op {
-    enum Kind { CONV, POOL, FINAL } kind;
+    enum Kind { CONV, POOL, FINAL, STEMPOOL } kind;
     ConvOp conv;
     TensorDesc pin, pout;
     int pk[6] = {0, 0, 0, 0, 0, 0};  // kh,kw,sh,sw,ph,pw
     const float* fw = nullptr;
     float fbias = 0.f;
     int final_slot = 0;  // 0 = probability, 1 = threshold
+    const half_t* spw = nullptr;  // STEMPOOL: fragment-ordered folded stem weights, bias
+    const float* spb = nullptr;
 };
 
 static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
@@ -247,6 +251,7 @@ struct vtd_detector : vtd::ModelBase {
     int64_t macs = 0;
     float* final_out[2] = {nullptr, nullptr};
     std::map<int, std::vector<int>> tuned;  // batch size -> tile config per op (-1 = heuristic)
+    bool fuse_stem_pool = true;  // conv7x7/s2 + BN + ReLU + maxpool3x3/s2 in one kernel (the 320x320x64 map is never written)
     bool fuse_fpn_head = true;  // compose FPN lateral(C2) + top-down add + P2 smooth + head conv into one classed conv
     // optional per-op HIP-event timing (bench / roofline accounting)
     bool profiling = false;
@@ -654,17 +659,35 @@ static int build_detector_graph(vtd_detector* d) {
 
     // stem + maxpool
     TensorDesc stem, x;
-    if ((rc = new_tensor(320, 320, 64, stem))) return rc;
-    {
+    if ((rc = new_tensor(160, 160, 64, x))) return rc;
+    if (d->fuse_stem_pool) {
+        Fold f;
+        if ((rc = fold_bn(d, "backbone.1", "", 64, f))) return rc;
+        auto w = d->get("backbone.0.weight", (size_t)64 * 3 * 7 * 7);
+        if (!w) return ERR_MISSING_KEY;
+        std::vector<float> wf(w->size());
+        for (int co = 0; co < 64; ++co)
+            for (int k = 0; k < 147; ++k) wf[(size_t)co * 147 + k] = (float)((double)(*w)[(size_t)co * 147 + k] * f.scale[co]);
+        std::vector<half_t> packed((size_t)7 * 4 * 64 * 8);
+        vtd_stem_pool_pack_weights(wf.data(), packed.data());
+        std::vector<float> bias(64);
+        for (int co = 0; co < 64; ++co) bias[co] = (float)f.shift[co];
+        Op o;
+        o.kind = Op::STEMPOOL;
+        o.pin = d->input; o.pout = x;
+        if ((rc = upload(d->arena, packed.data(), packed.size() * sizeof(half_t), (void**)&o.spw))) return rc;
+        if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&o.spb))) return rc;
+        o.conv.macs_per_image = (int64_t)320 * 320 * 64 * 147;
+        d->ops.push_back(o);
+        d->macs += o.conv.macs_per_image;
+    } else {
+        if ((rc = new_tensor(320, 320, 64, stem))) return rc;
         Fold f;
         if ((rc = fold_bn(d, "backbone.1", "", 64, f))) return rc;
         ConvOp c;
         if ((rc = build_stem(d, c, d->input, stem, "backbone.0.weight", f))) return rc;
         push_conv(c);
-    }
-    d->taps["stem"] = stem;
-    if ((rc = new_tensor(160, 160, 64, x))) return rc;
-    {
+        d->taps["stem"] = stem;
         Op o;
         o.kind = Op::POOL;
         o.pin = stem; o.pout = x;
@@ -672,6 +695,7 @@ static int build_detector_graph(vtd_detector* d) {
         std::memcpy(o.pk, pk, sizeof(pk));
         d->ops.push_back(o);
     }
+    d->taps["pool"] = x;
 
     // residual stages
     TensorDesc tapsC[4];
@@ -942,6 +966,7 @@ int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_
 int vtd_detector_set_option(vtd_detector* d, const char* name, int value) {
     if (!d || !name || d->finalized) return ERR_ARG;
     if (std::string(name) == "fuse_fpn_head") { d->fuse_fpn_head = value != 0; return 0; }
+    if (std::string(name) == "fuse_stem_pool") { d->fuse_stem_pool = value != 0; return 0; }
     return ERR_UNKNOWN_KEY;
 }
 
@@ -1008,6 +1033,7 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
             case Op::CONV: rc = launch_conv_op(o.conv, n, s, cfgs[oi]); break;
             case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
             case Op::FINAL: rc = launch_conv_op(o.conv, n, s, 7, outs[o.final_slot]); break;
+            case Op::STEMPOOL: rc = vtd_launch_stem_pool(o.pin, o.pout, o.spw, o.spb, n, s); break;
         }
         if (rc) return rc;
         if (d->profiling) {
@@ -1060,6 +1086,8 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                       c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
+    } else if (o.kind == Op::STEMPOOL) {
+        std::snprintf(name, name_cap, "stem_pool conv7x7/s2+BN+ReLU+maxpool3x3/s2 fused M/img=%d N=64 K=147", 320 * 320);
     } else {
         std::snprintf(name, name_cap, "conv_igemm<64,256,s2> ConvT1+ConvT2+sigmoid fused M/img=%d", o.conv.ho * o.conv.wo);
     }

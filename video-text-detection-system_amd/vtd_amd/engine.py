@@ -134,7 +134,7 @@ class DetectorEngine:
             return {"probability": prob, "threshold": thr}
 
     def read_tap(self, name, n):
-        shapes = {"input": (3, 640, 640), "stem": (64, 320, 320), "p2": (256, 160, 160), "head1": (64, 160, 160),
+        shapes = {"input": (3, 640, 640), "stem": (64, 320, 320), "pool": (64, 160, 160), "p2": (256, 160, 160), "head1": (64, 160, 160),
                   "head2": (64, 320, 320)}
         if name not in shapes:
             wide = self.backbone == "resnet50"
