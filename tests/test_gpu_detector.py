@@ -21,7 +21,7 @@ def _rel(a, b):
 def r18(hip):
     from vtd_amd.engine import DetectorEngine
     sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
-    eng = DetectorEngine("resnet18", sd, max_batch=4, options={"fuse_fpn_head": 0, "fuse_stem_pool": 0})  # layer-by-layer graph: every tap exists
+    eng = DetectorEngine("resnet18", sd, max_batch=4, options={"fuse_fpn_head": 0, "fuse_stem_pool": 0, "head_tail_kernel": 0})  # layer-by-layer graph: every tap exists
     yield eng, sd
     eng.close()
 

@@ -25,6 +25,10 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
                        hipStream_t stream);
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
+void vtd_head_tail_pack_w1(const half_t* w1_gemm, half_t* packed);
+void vtd_head_tail_pack_w2(const float* w2, half_t* packed);
+int vtd_launch_head_tail(const TensorDesc& in, const half_t* w1, const float* bias1, const half_t* w2, float b2, float* out, int n,
+                         hipStream_t stream);
 int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
 
 int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
@@ -102,7 +106,7 @@ struct ConvOp {
 };
 
 struct Op {
-    enum Kind { CONV, POOL, FINAL, STEMPOOL } kind;
+    enum Kind { CONV, POOL, FINAL, STEMPOOL, HEADTAIL } kind;
     ConvOp conv;
     TensorDesc pin, pout;
     int pk[6] = {0, 0, 0, 0, 0, 0};  // kh,kw,sh,sw,ph,pw
@@ -111,6 +115,8 @@ struct Op {
     int final_slot = 0;  // 0 = probability, 1 = threshold
     const half_t* spw = nullptr;  // STEMPOOL: fragment-ordered folded stem weights, bias
     const float* spb = nullptr;
+    const half_t* htw1 = nullptr;  // HEADTAIL: fragment-ordered ConvT1 / ConvT2 weights
+    const half_t* htw2 = nullptr;
 };
 
 static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
@@ -251,6 +257,7 @@ struct vtd_detector : vtd::ModelBase {
     int64_t macs = 0;
     float* final_out[2] = {nullptr, nullptr};
     std::map<int, std::vector<int>> tuned;  // batch size -> tile config per op (-1 = heuristic)
+    bool head_tail_kernel = true;  // dedicated persistent kernel for ConvT+BN+ReLU+ConvT+sigmoid (0: generic conv, 64x256 tile)
     bool fuse_stem_pool = true;  // conv7x7/s2 + BN + ReLU + maxpool3x3/s2 in one kernel (the 320x320x64 map is never written)
     bool fuse_fpn_head = true;  // compose FPN lateral(C2) + top-down add + P2 smooth + head conv into one classed conv
     // optional per-op HIP-event timing (bench / roofline accounting)
@@ -392,7 +399,7 @@ static int build_stem(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc
 
 // ConvTranspose2d(cin -> cout, k=2, s=2), weights [cin, cout, 2, 2]: GEMM with N = 4*cout and a pixel-shuffle store.
 static int build_convt(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey, const Fold& f,
-                       int cin, int cout, int flags) {
+                       int cin, int cout, int flags, std::vector<half_t>* host_w = nullptr) {
     auto w = d->get(wkey, (size_t)cin * cout * 4);
     if (!w) return ERR_MISSING_KEY;
     if (in.c != cin || (cin & 63) || out.h != 2 * in.h || out.w != 2 * in.w || out.c != cout || (cout & 15)) return ERR_GEOMETRY;
@@ -410,6 +417,7 @@ static int build_convt(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDes
     int rc;
     if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if (host_w) *host_w = wp;
     op.in = in; op.out = out; op.K = K; op.cout = N; op.cout_pad = cout_pad; op.stride = 1;
     op.in_y0 = in.ring; op.in_x0 = in.ring; op.flags = flags | EPI_PIXEL_SHUFFLE; op.ps_cout = cout;
     op.ho = in.h; op.wo = in.w;
@@ -812,7 +820,8 @@ static int build_detector_graph(vtd_detector* d) {
         // ConvT(64->64)+BN+ReLU and ConvT(64->1)+sigmoid in one launch: the 64x320x320 intermediate never touches HBM
         ConvOp c2;
         TensorDesc h2 = make_desc(B, 320, 320, 64, 1, 1);  // shape bookkeeping only (no allocation)
-        if ((rc = build_convt(d, c2, h1, h2, hp + "3.weight", f2, 64, 64, EPI_RELU))) return rc;
+        std::vector<half_t> w1_host;
+        if ((rc = build_convt(d, c2, h1, h2, hp + "3.weight", f2, 64, 64, EPI_RELU, &w1_host))) return rc;
         auto w6 = d->get(hp + "6.weight", 64 * 4), b6 = d->get(hp + "6.bias", 1);
         if (!w6 || !b6) return ERR_MISSING_KEY;
         std::vector<float> wf(4 * 64);
@@ -826,6 +835,14 @@ static int build_detector_graph(vtd_detector* d) {
         Op o1, o2;
         o1.kind = Op::CONV; o1.conv = c1; o1.final_slot = br;
         o2.kind = Op::FINAL; o2.conv = c2; o2.final_slot = br;
+        if (d->head_tail_kernel) {
+            std::vector<half_t> p1((size_t)4 * 4 * 2 * 64 * 8), p2((size_t)2 * 64 * 8);
+            vtd_head_tail_pack_w1(w1_host.data(), p1.data());
+            vtd_head_tail_pack_w2(wf.data(), p2.data());
+            if ((rc = upload(d->arena, p1.data(), p1.size() * sizeof(half_t), (void**)&o2.htw1))) return rc;
+            if ((rc = upload(d->arena, p2.data(), p2.size() * sizeof(half_t), (void**)&o2.htw2))) return rc;
+            o2.kind = Op::HEADTAIL;
+        }
         d->ops.push_back(o1);
         d->ops.push_back(o2);
         if (br == 0) {
@@ -967,6 +984,7 @@ int vtd_detector_set_option(vtd_detector* d, const char* name, int value) {
     if (!d || !name || d->finalized) return ERR_ARG;
     if (std::string(name) == "fuse_fpn_head") { d->fuse_fpn_head = value != 0; return 0; }
     if (std::string(name) == "fuse_stem_pool") { d->fuse_stem_pool = value != 0; return 0; }
+    if (std::string(name) == "head_tail_kernel") { d->head_tail_kernel = value != 0; return 0; }
     return ERR_UNKNOWN_KEY;
 }
 
@@ -1033,6 +1051,9 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
             case Op::CONV: rc = launch_conv_op(o.conv, n, s, cfgs[oi]); break;
             case Op::POOL: rc = vtd_launch_maxpool(o.pin, o.pout, n, o.pk[0], o.pk[1], o.pk[2], o.pk[3], o.pk[4], o.pk[5], s); break;
             case Op::FINAL: rc = launch_conv_op(o.conv, n, s, 7, outs[o.final_slot]); break;
+            case Op::HEADTAIL:
+                rc = vtd_launch_head_tail(o.conv.in, o.htw1, o.conv.bias, o.htw2, o.conv.head_b, outs[o.final_slot], n, s);
+                break;
             case Op::STEMPOOL: rc = vtd_launch_stem_pool(o.pin, o.pout, o.spw, o.spb, n, s); break;
         }
         if (rc) return rc;
@@ -1086,6 +1107,8 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                       c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
+    } else if (o.kind == Op::HEADTAIL) {
+        std::snprintf(name, name_cap, "head_tail ConvT1+BN+ReLU+ConvT2+sigmoid fused M/img=%d N=256 K=64", o.conv.ho * o.conv.wo);
     } else if (o.kind == Op::STEMPOOL) {
         std::snprintf(name, name_cap, "stem_pool conv7x7/s2+BN+ReLU+maxpool3x3/s2 fused M/img=%d N=64 K=147", 320 * 320);
     } else {
