@@ -50,7 +50,7 @@ def main():
     import numpy as np
     import torch
     from vtd_amd import synth, weights
-    from vtd_amd.engine import DetectorEngine, DeviceFrames, PostProcessor, detector_profile
+    from vtd_amd.engine import DeviceFrames, detector_profile
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,26 +80,28 @@ def main():
     rec_sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
     pipe.recognizer.model.load_state_dict(rec_sd)
     eng = pipe.detector.model.engine()
-    pp = pipe.detector._postprocessor(640, 640, B)
-    prob = torch.empty((B, 1, 640, 640), dtype=torch.float32, device="cuda")
-    import ctypes as C
-    from vtd_amd import _native
     lib = eng.lib
     last = {}
 
+    inflight = {"det": None, "rec": None}
+
     def step_detector():
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _native.check(lib.vtd_detector_preprocess(eng.handle, C.c_void_p(dev_frames.tensor.data_ptr()), B, H, W, s))
-        _native.check(lib.vtd_detector_forward(eng.handle, B, C.c_void_p(prob.data_ptr()), None, s))
-        rec, cnt = pp.run_device(prob, [W] * B, [H] * B, 0.5)
-        last["n_det"] = cnt
-        return rec, cnt
+        # the product's detector half, two batches in flight: enqueue batch i (preprocess -> DBNet on the caller's stream,
+        # post-process + record copy on the side stream), then turn the records of batch i-1 into the result dicts
+        t = pipe.detector.submit_batch(dev_frames, 0.5)
+        if inflight["det"] is not None:
+            last["detections"] = pipe.detector.finish_batch(inflight["det"])
+        inflight["det"] = t
+        return t["keep"][1][:B], t["keep"][2][:B]
+
+    def drain_detector():
+        if inflight["det"] is not None:
+            last["detections"] = pipe.detector.finish_batch(inflight["det"])
+            inflight["det"] = None
 
     # full workload: the product's batched pass, software-pipelined three deep exactly as a video loop would run it --
     # detector(i) is enqueued, then the host collects the boxes of batch i-1 and enqueues its recogniser, then builds
     # the result dicts of batch i-2.  Every step retires one whole batch (result dicts included).
-    inflight = {"det": None, "rec": None}
-
     def step_full():
         job = pipe.submit_detection(dev_frames)
         keep = job["det"]["keep"]
@@ -131,18 +133,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    drain = drain_full if args.workload == "full" else drain_detector
     for _ in range(args.warmup):
         step()
-    if args.workload == "full":
-        drain_full()
+    drain()
     barrier()
     if not args.no_profile:
         lib.vtd_detector_set_profiling(eng.handle, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec, cnt = step()
-    if args.workload == "full":
-        drain_full()  # K batches submitted -> K batches retired inside the timed region
+    drain()  # K batches submitted -> K batches retired (result dicts built) inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -20,6 +20,7 @@
 //                  or fp32 row-major output
 //   scheduling     one workgroup per BM x BN tile; the linear block id is re-dealt so that the 8 XCDs each own a
 //                  contiguous run of tiles (neighbouring tiles share halo rows and the weight panel in that L2)
+#include <cstdlib>
 #include "vtd_common.h"
 
 namespace {
@@ -114,8 +115,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // One LDS-DMA instruction (1 KB) of K-step `ks` into buffer `buf`: j < A_INST feeds the A tile, the rest the B tile.
     auto issue_load = [&](int j, int ks, int buf) {
         char* abase = smem + buf * STAGE;
+        if (p.dbg >= 3) return;
         if (j < A_INST) {
-            const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + kb;
+            if (p.dbg == 2) return;
+            const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + (p.dbg == 1 ? 0 : kb);
             __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (j * NW + w) * 1024), 16, 0, 0);
         } else {
             const int i = j - A_INST;
@@ -452,7 +455,10 @@ int vtd_conv_default_config(const ConvParams& p) {
 
 // Host entry used by the network graphs in vtd_api.cpp.  Shapes are validated here: a mismatch must
 // never reach the kernel (an out-of-bounds gather can take the whole node down).
-int vtd_launch_conv(const ConvParams& p, int cfg, hipStream_t stream) {
+int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
+    static const int dbg = [] { const char* e = getenv("VTD_CONV_DEBUG"); return e ? atoi(e) : 0; }();
+    ConvParams p = p_in;
+    p.dbg = dbg;
     if (p.M <= 0 || p.K <= 0 || (p.K & 63) || p.cout <= 0 || (p.cout_pad & 63) || p.cout > p.cout_pad) return -1001;
     if ((p.cout & 7) && !(p.flags & EPI_OUT_F32)) return -1002;
     if ((p.flags & EPI_OUT_F32) && (p.ldc & 3)) return -1003;

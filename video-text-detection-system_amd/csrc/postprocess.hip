@@ -18,6 +18,7 @@
 // All stages are HBM/L2-bound integer work; no host synchronisation happens between them.
 #include <float.h>
 #include <math.h>
+#include <vector>
 
 #include "../../include/vtd.h"
 #include "vtd_common.h"
@@ -678,6 +679,7 @@ struct vtd_postproc {
     void* blocks[24];
     int nblocks = 0;
     int *orig_w_dev = nullptr, *orig_h_dev = nullptr;
+    std::vector<int> orig_shadow;  // host copy of (w, h) per frame as last uploaded
 };
 
 static int pp_alloc(vtd_postproc* pp, void** out, size_t bytes) {
@@ -744,8 +746,18 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     for (int i = 0; i < n; ++i)
         if (orig_w_host[i] <= 0 || orig_h_host[i] <= 0) return -1100;
     hipStream_t s = (hipStream_t)stream;
-    VTD_HIP_CHECK(hipMemcpyAsync(pp->orig_w_dev, orig_w_host, n * 4, hipMemcpyHostToDevice, s));
-    VTD_HIP_CHECK(hipMemcpyAsync(pp->orig_h_dev, orig_h_host, n * 4, hipMemcpyHostToDevice, s));
+    // Frame sizes rarely change between calls: the device copy is refreshed only when they do.  (An asynchronous copy from
+    // pageable memory makes the host wait for the stream to reach it, i.e. for the whole detector in front of this call,
+    // and that would serialise the caller's batch pipeline.)  On a change: drain the stream, then copy synchronously.
+    bool same = (int)pp->orig_shadow.size() >= 2 * n;
+    for (int i = 0; same && i < n; ++i) same = pp->orig_shadow[2 * i] == orig_w_host[i] && pp->orig_shadow[2 * i + 1] == orig_h_host[i];
+    if (!same) {
+        VTD_HIP_CHECK(hipDeviceSynchronize());
+        VTD_HIP_CHECK(hipMemcpy(pp->orig_w_dev, orig_w_host, n * 4, hipMemcpyHostToDevice));
+        VTD_HIP_CHECK(hipMemcpy(pp->orig_h_dev, orig_h_host, n * 4, hipMemcpyHostToDevice));
+        if ((int)pp->orig_shadow.size() < 2 * n) pp->orig_shadow.resize(2 * n, 0);
+        for (int i = 0; i < n; ++i) { pp->orig_shadow[2 * i] = orig_w_host[i]; pp->orig_shadow[2 * i + 1] = orig_h_host[i]; }
+    }
     PostWs ws = pp->ws;
     ws.prob = prob_dev; ws.n = n; ws.thr = threshold;
     ws.orig_w = pp->orig_w_dev; ws.orig_h = pp->orig_h_dev;

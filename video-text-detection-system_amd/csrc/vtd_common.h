@@ -59,6 +59,7 @@ struct ConvParams {
     int res_hp, res_wp, res_ring, res_shift;
     int ps_cout;           // pixel-shuffle: channels per (ky,kx) block
     int flags;
+    int dbg;               // timing experiments only (VTD_CONV_DEBUG): 1 = A gather pinned to tap 0, 2 = no A loads, 3 = no loads
     int ldc;               // EPI_OUT_F32 row stride
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row

@@ -114,7 +114,14 @@ class TextDetector:
         n = batch.n
         prob = self.model(batch)["probability"]
         pp = self._postprocessor(prob.shape[-2], prob.shape[-1], n)
-        with pp.lock:
+        # The post-process (a dependent chain of narrow kernels) runs on its own HIP stream behind an event: the caller's
+        # stream is free for the next batch's preprocess + DBNet at once and the two overlap on the GPU.
+        side = self._post_stream()
+        if side is not None:
+            done = torch.cuda.Event()
+            done.record()
+            side.wait_event(done)
+        with pp.lock, torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
             records = torch.empty((n, pp.max_out, 16), dtype=torch.int32, device="cuda")
             counts = torch.empty((n,), dtype=torch.int32, device="cuda")
             pp.run_device(prob.reshape(n, prob.shape[-2], prob.shape[-1]), [batch.width] * n, [batch.height] * n,
@@ -126,6 +133,13 @@ class TextDetector:
             ev = torch.cuda.Event()
             ev.record()
         return {"rec": host_rec, "cnt": host_cnt, "event": ev, "max_out": pp.max_out, "keep": (prob, records, counts, batch)}
+
+    def _post_stream(self):
+        if os.environ.get("VTD_POST_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
 
     @staticmethod
     def finish_batch(ticket):

@@ -13,12 +13,14 @@ resident in HBM.  The reference-shaped route is kept and taken whenever the test
 tests/test_integration.py:54-79 of the reference), or when frames of a batch differ in size.
 """
 import asyncio
+import os
 import logging
 import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
+import torch
 
 logger = logging.getLogger(__name__)
 
@@ -137,8 +139,25 @@ class VideoTextPipeline:
                 if x2 > x1 and y2 > y1:
                     boxes.append((i, x1, y1, x2, y2))
                     owners.append((i, j))
-        job.update(detections=detections, owners=owners, rec=self.recognizer.submit_boxes(job["batch"], boxes))
+        # The recogniser of batch i runs on its own HIP stream: it is independent of the detector of batch i+1 that is
+        # already queued on the caller's stream, and its narrow kernels (LSTM recurrence: 17 workgroups, CTC decode, crop)
+        # then fill CUs the detector's convolutions leave idle between launches instead of serialising behind them.
+        stream = self._recognizer_stream()
+        if stream is None:
+            rec = self.recognizer.submit_boxes(job["batch"], boxes)
+        else:
+            stream.wait_event(job["det"]["event"])  # frames uploaded + detector done with them, in stream order
+            with torch.cuda.stream(stream):
+                rec = self.recognizer.submit_boxes(job["batch"], boxes)
+        job.update(detections=detections, owners=owners, rec=rec)
         return job
+
+    def _recognizer_stream(self):
+        if os.environ.get("VTD_REC_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_rec_stream", None) is None:
+            self._rec_stream = torch.cuda.Stream()
+        return self._rec_stream
 
     def collect(self, job, frame_info=None) -> List[Dict]:
         n = job["batch"].n
