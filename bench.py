@@ -138,8 +138,19 @@ def main():
         step()
     drain()
     barrier()
+    # Untimed survey pass: every launch of the detector graph bracketed with HIP events -> per-launch table and the identity
+    # of the dominant launch.  The timed region then brackets only that launch (2 events per step).
+    survey, dom = [], -1
     if not args.no_profile:
         lib.vtd_detector_set_profiling(eng.handle, 1)
+        for _ in range(3):  # one batch at a time, drained: every launch has the GPU to itself (no other stream running)
+            step()
+            drain()
+            torch.cuda.synchronize()
+        barrier()
+        survey = detector_profile(eng)
+        dom = max(range(len(survey)), key=lambda i: survey[i][1] if survey[i][3] > 0 else -1.0)
+        lib.vtd_detector_set_profiling(eng.handle, 2 + dom)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec, cnt = step()
@@ -158,18 +169,18 @@ def main():
     roofline = None
     layer_rows = []
     if not args.no_profile:
-        prof = detector_profile(eng)
+        timed = detector_profile(eng)  # only slot `dom` carries events from the timed region
         lib.vtd_detector_set_profiling(eng.handle, 0)
         convs = []
-        for name, ms, calls, macs in prof:
+        for name, ms, calls, macs in survey:
             layer_rows.append({"launch": name, "ms_total": ms, "calls": calls, "gmac_total": macs / 1e9,
                                "tflops": (2 * macs / (ms * 1e-3) / 1e12) if ms > 0 and macs > 0 else None})
             if macs > 0 and calls > 0:
-                convs.append((name, ms, calls, macs))
-        # dominant kernel = the single launch of the detector graph with the largest share of the timed region
-        name, ms, calls, macs = max(convs, key=lambda r: r[1])
+                convs.append((name, ms / calls, macs / calls))
+        name, ms, calls, macs = timed[dom]
         achieved = 2 * macs / (ms * 1e-3) / 1e12
-        conv_ms = sum(r[1] for r in convs)
+        iso_ms, iso_calls, iso_macs = survey[dom][1], survey[dom][2], survey[dom][3]
+        conv_us = sum(r[1] for r in convs) * 1e3  # per step, survey pass
         # algorithmic (reference-graph) FLOPs of the whole detector per step, SURVEY 8d: 69.8 GFLOP / frame for R18
         algo_flops_step = 2.0 * eng.macs_per_frame * B
         traffic = None
@@ -188,12 +199,17 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
                     "executed_gflop_per_launch": round(2 * macs / calls / 1e9, 3),
+                    "alone_on_gpu": {"avg_launch_us": round(iso_ms / iso_calls * 1e3, 2),
+                                     "tflops": round(2 * iso_macs / (iso_ms * 1e-3) / 1e12, 2),
+                                     "frac": round(2 * iso_macs / (iso_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                     "what": "same launch in the untimed survey pass, one batch at a time: in the timed region the "
+                                             "recogniser and post-process streams share the CUs with it, which stretches its wall time"},
                     "note": "achieved = FLOPs this launch EXECUTES / its HIP-event time on the launch stream; the composed conv replaces "
                             "lateral(C2)+top-down add+P2 smooth+head conv of the reference graph with ~3x fewer FLOPs, so the "
                             "reference-graph rate over all matrix launches is given as net_algorithmic_tflops",
-                    "all_mfma_launches_tflops_executed": round(sum(2 * r[3] for r in convs) / (conv_ms * 1e-3) / 1e12, 2),
-                    "net_algorithmic_tflops": round(algo_flops_step * args.steps / (conv_ms * 1e-3) / 1e12, 2),
-                    "mfma_launch_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 3)}
+                    "all_mfma_launches_tflops_executed": round(sum(2 * r[2] for r in convs) / (conv_us * 1e-6) / 1e12, 2),
+                    "net_algorithmic_tflops": round(algo_flops_step / (conv_us * 1e-6) / 1e12, 2),
+                    "detector_mfma_launches_us_per_step": round(conv_us, 1)}
         if args.layers_out and rank == 0:
             with open(args.layers_out, "w") as f:
                 json.dump(layer_rows, f, indent=1)

@@ -79,7 +79,8 @@ int vtd_detector_read_tap(vtd_detector* d, const char* name, int n, float* host_
 /* Algorithmic live work of one frame through this detector, in MACs (for roofline accounting). */
 int64_t vtd_detector_macs_per_frame(const vtd_detector* d);
 /* Per-launch HIP-event timing on the launch stream (bench.py's roofline leg).  set_profiling(1) resets the
- * accumulators; while enabled every vtd_detector_forward brackets each of its launches with events.
+ * accumulators; while enabled every vtd_detector_forward brackets each of its launches with events (enable = 2 + k:
+ * only launch slot k, two events per forward, so the timed region is not perturbed).
  * get_profile resolves pending events (synchronises the stream) and returns, for launch slot op_index in
  * [0, vtd_detector_num_ops), a description, the accumulated milliseconds, launch count and algorithmic MACs. */
 int vtd_detector_set_profiling(vtd_detector* d, int enable);

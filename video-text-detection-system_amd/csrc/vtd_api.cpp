@@ -262,6 +262,7 @@ struct vtd_detector : vtd::ModelBase {
     bool fuse_fpn_head = true;  // compose FPN lateral(C2) + top-down add + P2 smooth + head conv into one classed conv
     // optional per-op HIP-event timing (bench / roofline accounting)
     bool profiling = false;
+    int prof_only = -1;  // >= 0: only this launch slot is bracketed with events
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_spans;  // op index -> (start, stop)
@@ -1041,7 +1042,8 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
         int rc = 0;
         if (o.final_slot == 1 && !thresh_dev) continue;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (d->profiling) {
+        const bool prof = d->profiling && (d->prof_only < 0 || d->prof_only == (int)oi);
+        if (prof) {
             e0 = d->take_event();
             e1 = d->take_event();
             if (!e0 || !e1) return ERR_ARG;
@@ -1057,7 +1059,7 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
             case Op::STEMPOOL: rc = vtd_launch_stem_pool(o.pin, o.pout, o.spw, o.spb, n, s); break;
         }
         if (rc) return rc;
-        if (d->profiling) {
+        if (prof) {
             VTD_HIP_CHECK(hipEventRecord(e1, s));
             d->ev_spans.push_back({(int)oi, {e0, e1}});
             d->prof_macs[oi] += (o.kind != Op::POOL) ? (double)o.conv.macs_per_image * n : 0.0;
@@ -1069,6 +1071,8 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
 int vtd_detector_set_profiling(vtd_detector* d, int enable) {
     if (!d || !d->finalized) return ERR_ARG;
     d->profiling = enable != 0;
+    d->prof_only = enable >= 2 ? enable - 2 : -1;
+    if (d->prof_only >= (int)d->ops.size()) return ERR_ARG;
     d->ev_spans.clear();
     d->ev_used = 0;
     d->prof_ms.assign(d->ops.size(), 0.0);
