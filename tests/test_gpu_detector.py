@@ -129,6 +129,39 @@ def test_dbnet_fused_stem_pool(r18, r18_fused):
         eng_f.read_tap("stem", 1)  # never materialised
 
 
+def test_dbnet_halo_conv_forced(hip, monkeypatch):
+    """conv_halo.hip (3x3 stride-1 layers with the input halo staged once in LDS) forced wherever it applies -- 160x160,
+    80x80 and 40x40 (partial 16x16 pixel blocks) maps, with and without residual: taps and probabilities against the fp32
+    oracle at the same tolerances as the implicit-GEMM path, and against that path itself."""
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(21))
+    ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VTD_FORCE_HALO", mode)
+        monkeypatch.setenv("VTD_HALO_CONV", mode)
+        eng = DetectorEngine("resnet18", sd, max_batch=2, options={"fuse_fpn_head": 0})
+        try:
+            prob = eng.forward(x)["probability"].cpu().numpy()
+            taps = [eng.read_tap(n, 2) for n in ("c2", "c3", "c4", "c5", "p2")]
+            from vtd_amd.engine import detector_profile
+            names = [row[0] for row in detector_profile(eng)]
+        finally:
+            eng.close()
+        outs[mode] = (prob, taps, names)
+    prob, taps, names = outs["1"]
+    errs = {n: _rel(taps[i], ref["taps"][i].numpy()) for i, n in enumerate(("c2", "c3", "c4", "c5"))}
+    errs["p2"] = _rel(taps[4], ref["p2"].numpy())
+    dp = float(np.abs(prob - ref["probability"].numpy()).max())
+    d_paths = float(np.abs(prob - outs["0"][0]).max())
+    print("halo path tap errors", errs, "max|dp|", dp, "vs implicit-GEMM path", d_paths, "halo launches", sum("conv_halo" in n for n in names))
+    assert all(v < 1.5e-2 for v in errs.values()), errs
+    assert dp <= 2e-3 and d_paths <= 2e-3
+    assert sum("conv_halo" in n for n in names) >= 7  # layer1 (4) + layer2 (3) at least
+    assert not any("conv_halo" in n for n in outs["0"][2])
+
+
 def test_dbnet_batch_independence_and_threshold_branch(r18):
     eng, sd = r18
     x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(10))

@@ -25,6 +25,8 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
                        hipStream_t stream);
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
+bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
+int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
 void vtd_head_tail_pack_w1(const half_t* w1_gemm, half_t* packed);
 void vtd_head_tail_pack_w2(const float* w2, half_t* packed);
 int vtd_launch_head_tail(const TensorDesc& in, const half_t* w1, const float* bias1, const half_t* w2, float b2, float* out, int n,
@@ -140,10 +142,22 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     }
 }
 
+// Tile "configuration" kHaloCfg selects the halo-tile kernel (conv_halo.hip) instead of an implicit-GEMM tile shape.
+static const int kHaloCfg = 100;
+static bool halo_enabled() {
+    const char* e = std::getenv("VTD_HALO_CONV");
+    return !(e && e[0] == '0');
+}
+
 static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, float* prob_out = nullptr) {
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
+    if (cfg == kHaloCfg) {
+        int bn = 0, tw = 0;
+        if (!vtd_conv_halo_supported(p, &bn, &tw)) return ERR_GEOMETRY;
+        return vtd_launch_conv_halo(p, bn, tw, s);
+    }
     return vtd_launch_conv(p, cfg, s);
 }
 
@@ -167,6 +181,20 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; best_id = cfg; }
+    }
+    int hbn = 0, htw = 0;
+    if (!rc && halo_enabled() && vtd_conv_halo_supported(p, &hbn, &htw)) {
+        const char* force = std::getenv("VTD_FORCE_HALO");  // tests: take the halo kernel wherever it applies
+        if (force && force[0] == '1') best = 1e30f;
+        if (!(rc = vtd_launch_conv_halo(p, hbn, htw, s))) {
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_conv_halo(p, hbn, htw, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (!rc && ms < best) { best = ms; best_id = kHaloCfg; }
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1107,8 +1135,11 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                                       "64,256,s2", "128,64,s2,classed", "128,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 10) ? kTile[cfg] : "default",
-                      c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
+        if (cfg == kHaloCfg)
+            std::snprintf(name, name_cap, "conv_halo 3x3 M/img=%d N=%d K=%d", c.ho * c.wo, c.cout, c.K);
+        else
+            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 10) ? kTile[cfg] : "default",
+                          c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
     } else if (o.kind == Op::HEADTAIL) {
@@ -1118,9 +1149,10 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     } else {
         std::snprintf(name, name_cap, "conv_igemm<64,256,s2> ConvT1+ConvT2+sigmoid fused M/img=%d", o.conv.ho * o.conv.wo);
     }
-    *total_ms = d->prof_ms[op_index];
-    *calls = d->prof_calls[op_index];
-    *total_macs = d->prof_macs[op_index];
+    const bool have = d->prof_ms.size() == d->ops.size();  // set_profiling never called: names only
+    *total_ms = have ? d->prof_ms[op_index] : 0.0;
+    *calls = have ? d->prof_calls[op_index] : 0;
+    *total_macs = have ? d->prof_macs[op_index] : 0.0;
     return 0;
 }
 

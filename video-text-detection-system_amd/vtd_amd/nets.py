@@ -13,6 +13,8 @@ Repairs relative to the as-shipped reference: the
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -145,7 +147,10 @@ class DBNet(nn.Module):
         if self._engine is None or self._engine_version != self._version:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict(), getattr(self, "_max_batch", None))
+            # VTD_DETECTOR_OPTIONS="fuse_fpn_head=0,fuse_stem_pool=0": build options for A/B measurements (include/vtd.h)
+            opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_DETECTOR_OPTIONS", "").split(",") if kv)}
+            self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict(), getattr(self, "_max_batch", None),
+                                             options=opts or None)
             self._engine_version = self._version
         return self._engine
 
