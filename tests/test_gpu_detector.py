@@ -138,9 +138,9 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
     x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(21))
     ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
     outs = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "2", "0"):
         monkeypatch.setenv("VTD_FORCE_HALO", mode)
-        monkeypatch.setenv("VTD_HALO_CONV", mode)
+        monkeypatch.setenv("VTD_HALO_CONV", "0" if mode == "0" else "1")
         eng = DetectorEngine("resnet18", sd, max_batch=2, options={"fuse_fpn_head": 0})
         try:
             prob = eng.forward(x)["probability"].cpu().numpy()
@@ -150,15 +150,19 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
         finally:
             eng.close()
         outs[mode] = (prob, taps, names)
-    prob, taps, names = outs["1"]
-    errs = {n: _rel(taps[i], ref["taps"][i].numpy()) for i, n in enumerate(("c2", "c3", "c4", "c5"))}
-    errs["p2"] = _rel(taps[4], ref["p2"].numpy())
-    dp = float(np.abs(prob - ref["probability"].numpy()).max())
-    d_paths = float(np.abs(prob - outs["0"][0]).max())
-    print("halo path tap errors", errs, "max|dp|", dp, "vs implicit-GEMM path", d_paths, "halo launches", sum("conv_halo" in n for n in names))
-    assert all(v < 1.5e-2 for v in errs.values()), errs
-    assert dp <= 2e-3 and d_paths <= 2e-3
-    assert sum("conv_halo" in n for n in names) >= 7  # layer1 (4) + layer2 (3) at least
+    for mode in ("1", "2"):  # 2 = layer1 additionally on the persistent resident-weight variant
+        prob, taps, names = outs[mode]
+        errs = {n: _rel(taps[i], ref["taps"][i].numpy()) for i, n in enumerate(("c2", "c3", "c4", "c5"))}
+        errs["p2"] = _rel(taps[4], ref["p2"].numpy())
+        dp = float(np.abs(prob - ref["probability"].numpy()).max())
+        d_paths = float(np.abs(prob - outs["0"][0]).max())
+        print("halo mode", mode, "tap errors", errs, "max|dp|", dp, "vs implicit-GEMM path", d_paths,
+              "halo launches", sum("conv_halo" in n for n in names), "persistent", sum("c64_persistent" in n for n in names))
+        assert all(v < 1.5e-2 for v in errs.values()), errs
+        assert dp <= 2e-3 and d_paths <= 2e-3
+        assert sum("conv_halo" in n for n in names) >= 7  # layer1 (4) + layer2 (3) at least
+        if mode == "2":
+            assert sum("c64_persistent" in n for n in names) == 4
     assert not any("conv_halo" in n for n in outs["0"][2])
 
 
@@ -168,7 +172,10 @@ def test_dbnet_batch_independence_and_threshold_branch(r18):
     full = eng.forward(x, want_threshold=True)
     one = eng.forward(x[1:2])
     torch.cuda.synchronize()
-    assert torch.equal(full["probability"][1], one["probability"][0])
+    # frames of a batch do not influence one another.  Not bit-equal: the per-batch-size autotune may pick a different kernel
+    # (implicit GEMM / halo tile / persistent) for n = 3 and n = 1 and those differ in fp32 summation order; an order of
+    # magnitude below the 2e-3 parity tolerance is the bar.
+    assert float((full["probability"][1] - one["probability"][0]).abs().max()) <= 2e-4
     ref = onets.dbnet_forward(x[:1], sd, "resnet18", want_threshold=True)
     assert float((full["threshold"][0].cpu() - ref["threshold"][0]).abs().max()) <= 2e-3
 

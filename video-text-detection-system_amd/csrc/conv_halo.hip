@@ -214,6 +214,237 @@ __global__ __launch_bounds__((BN / 64) * 256) void conv_halo_kernel(const HaloPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (ResNet layer1): PERSISTENT workgroups with the whole 3x3x64x64 weight set resident in LDS.
+// Measured on the kernel above (VTD_HALO_STAMPS): an LDS-DMA takes ~2 us to land, so a 3-stage weight ring leaves the matrix
+// pipe waiting on memory 80 % of the time when a K-step is only 0.2 us of MFMA work.  For Cin = Cout = 64 the weights are
+// 72 KB: they are loaded ONCE per workgroup, the halo of the next pixel block is fetched a whole block (~2 us of MFMAs)
+// ahead into the other halo buffer, and the K loop has no barrier and no wait in it at all.  LDS: 72 KB weights + 2 x 41 KB
+// halo = 154 KB, one 4-wave workgroup per CU.  The weight rows are permuted in LDS so that a lane's 16 accumulators of a pixel
+// are 16 consecutive channels: residual and output move as 16-byte pieces straight from / to HBM, no staging tile.
+template <int TW, bool RELU, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_persistent_kernel(const HaloParams p) {
+    constexpr int TH = 256 / TW, HWD = TW + 2, HROWS = (TH + 2) * HWD, HPIECES = (HROWS + 7) / 8, HBYTES = HPIECES * 1024;
+    constexpr int HPW = (HPIECES + 3) / 4;  // halo pieces per wave (every wave issues exactly HPW loads: uniform vmcnt)
+    constexpr int WBYTES = 9 * 64 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wl = smem;                       // [9 taps][64 cout][128 B], 16-byte chunks swizzled by (cout >> 1) & 7
+    char* const hbuf = smem + WBYTES;            // 2 halo buffers (+ 1 KB landing pad for the padding loads)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 3, fr = lane & 15, fq = lane >> 4;
+    const int tiles_per_img = p.tiles_x * p.tiles_y, total = p.n * tiles_per_img;
+
+    // ---- weights: 72 one-KB pieces, 18 per wave, once
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int piece = w + 4 * k, tap = piece >> 3, row = (piece & 7) * 8 + lrow;
+        const int c_log = (lane & 7) ^ ((row >> 1) & 7);
+        // LDS row = MFMA fragment i (row >> 4), fragment row rho (row & 15); it carries output channel 16*(rho>>2) + 4*i + (rho&3),
+        // so that the lane group q = rho>>2 ends up owning the 16 CONSECUTIVE channels 16q .. 16q+15 of its pixels
+        const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);
+        __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.wgt + cout * 576 + tap * 64 + c_log * 8),
+                                         (VTD_AS3 void*)(wl + piece * 1024), 16, 0, 0);
+    }
+    floatx4 bias4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = *(const floatx4*)(p.bias + fq * 16 + i * 4);
+    // consume the bias here: otherwise its first use (accumulator init) sits inside the block loop and the compiler parks an
+    // s_waitcnt vmcnt(0) there, which would wait for the NEXT block's halo in every iteration
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bias4[i]));
+
+    auto tile_coords = [&](int t, int& img, int& y0, int& x0) {
+        img = t / tiles_per_img;
+        const int r = t - img * tiles_per_img, ty = r / p.tiles_x;
+        y0 = ty * TH;
+        x0 = (r - ty * p.tiles_x) * TW;
+    };
+    // Per-lane source offset of each halo piece relative to the block's first halo pixel, and the LDS destination: both are
+    // block independent (the launcher guarantees whole blocks: h % TH == 0, w % TW == 0), so a block costs one add per piece.
+    int hrel[HPW];
+    int hdst[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int piece = w + 4 * k;
+        int row = piece * 8 + lrow;
+        row = row < HROWS ? row : HROWS - 1;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        hrel[k] = (hy * p.in_wp + hx) * 64 + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        hdst[k] = piece < HPIECES ? WBYTES + piece * 1024 : WBYTES + 2 * HBYTES;
+    }
+    auto issue_halo = [&](int img, int y0, int x0, int buf) {
+        const half_t* base = p.in + ((int64_t)(img * p.in_hp + y0 - 1 + p.in_ring) * p.in_wp + x0 - 1 + p.in_ring) * 64;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k)
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(base + hrel[k]),
+                                             (VTD_AS3 void*)(smem + hdst[k] + (w + 4 * k < HPIECES ? buf * HBYTES : 0)), 16, 0, 0);
+    };
+    // likewise for the residual / output pixels of this lane's four fragments
+    int orel[4], rrel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = w * 64 + j * 16 + fr;
+        orel[j] = ((m / TW) * p.out_wp + (m % TW)) * 64 + fq * 16;
+        rrel[j] = ((m / TW) * p.res_wp + (m % TW)) * 64 + fq * 16;
+    }
+
+    int hbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = w * 64 + j * 16 + fr;
+        hbase[j] = (m / TW) * HWD + (m % TW);
+    }
+    const int bswz = (fr >> 1) & 7;
+
+    auto load_res = [&](int img, int y0, int x0, half8 (&rv)[4][2]) {
+        const half_t* rbase = p.res + ((int64_t)(img * p.res_hp + y0 + p.res_ring) * p.res_wp + x0 + p.res_ring) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rv[j][0] = *(const half8*)(rbase + rrel[j]);
+            rv[j][1] = *(const half8*)(rbase + rrel[j] + 8);
+        }
+    };
+
+    // Block schedule: at the top of block b the residual(b) loads and the halo(b+1) LDS-DMA go out, then a counted wait for
+    // halo(b) (issued a whole block earlier), then the barrier-free K loop, then the epilogue.  (A schedule that moves the
+    // counted wait in front of the stores -- on gfx9 stores share vmcnt with loads but retire out of order with them, so the
+    // wait below also sits out the previous block's store acks -- was tried and lost: the compiler answers the extra live
+    // loads with s_waitcnt vmcnt(0) at the loop head.)
+    int tile = blockIdx.x;
+    if (tile >= total) return;  // (grid <= total: never taken)
+    int img, y0, x0;
+    tile_coords(tile, img, y0, x0);
+    issue_halo(img, y0, x0, 0);
+    int cur = 0;
+    unsigned long long acc_wait = 0, acc_loop = 0, acc_epi = 0, t_a = 0, t_b = 0, t_c = 0;
+    for (; tile < total; tile += gridDim.x, cur ^= 1) {
+        if (p.stamps) t_a = __builtin_amdgcn_s_memtime();
+        const int ntile = tile + gridDim.x;
+        int nimg = img, ny0 = y0, nx0 = x0;
+        half8 rv[4][2];
+        if (RES) load_res(img, y0, x0, rv);
+        if (ntile < total) tile_coords(ntile, nimg, ny0, nx0);
+        issue_halo(nimg, ny0, nx0, cur ^ 1);  // past the last block: a harmless reload (keeps the load count uniform)
+        // everything older than the HPW (+8) loads just issued has landed: weights and this block's halo
+        if (RES) hl_wait_vmcnt<HPW + 8>(); else hl_wait_vmcnt<HPW>();
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps) t_b = __builtin_amdgcn_s_memtime();
+
+        floatx4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = bias4[i];
+        const char* hb = hbuf + cur * HBYTES;
+        // 18 half K-steps (tap, 32 channels), software pipelined by hand: one wave per SIMD has nobody to hide its LDS latency
+        // behind, so the 8 fragment reads of half-step h+1 are issued ahead of the 16 MFMAs of half-step h (pinned below).
+        auto load_frags = [&](int hs, half8 (&af)[4], half8 (&bf)[4]) {
+            const int tap = hs >> 1, kk = hs & 1;
+            const int tapoff = (tap / 3) * HWD + (tap % 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int hrow = hbase[j] + tapoff;
+                af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ ((hrow >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(wl + tap * 8192 + (i * 16 + fr) * 128 + (((fq + 4 * kk) ^ bswz) << 4));
+        };
+        half8 fa[2][4], fb[2][4];
+        load_frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int hs = 0; hs < 18; ++hs) {
+            if (hs + 1 < 18) load_frags(hs + 1, fa[(hs + 1) & 1], fb[(hs + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[hs & 1][i], fa[hs & 1][j], acc[i][j], 0, 0, 0);
+            if (hs + 1 < 18) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 fragment reads of half-step h+1 go out first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // ... and are in flight under the 16 MFMAs of half-step h
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep each half-step's prefetch inside its own half-step
+        }
+
+        // ---- epilogue: (+ residual) -> ReLU -> fp16; a lane owns channels 16fq..16fq+15 of its four pixels: 16-byte stores
+        if (p.stamps) {
+            asm volatile("s_nop 0" ::"v"(acc[3][3][3]));
+            t_c = __builtin_amdgcn_s_memtime();
+        }
+        half_t* obase = p.out + ((int64_t)(img * p.out_hp + y0 + p.out_ring) * p.out_wp + x0 + p.out_ring) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                half8 hv;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = acc[2 * h + (k >> 2)][j][k & 3];
+                    if (RES) v += (float)rv[j][h][k];
+                    hv[k] = (half_t)(RELU ? fmaxf(v, 0.f) : v);
+                }
+                *(half8*)(obase + orel[j] + h * 8) = hv;
+            }
+        __builtin_amdgcn_s_barrier();  // every wave is done with this halo buffer before the block after next lands in it
+        img = nimg; y0 = ny0; x0 = nx0;
+        if (p.stamps) {
+            const unsigned long long t_d = __builtin_amdgcn_s_memtime();
+            acc_wait += t_b - t_a; acc_loop += t_c - t_b; acc_epi += t_d - t_c;
+        }
+    }
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + (int64_t)blockIdx.x * 4;
+        o[0] = 0; o[1] = acc_wait; o[2] = acc_wait + acc_loop; o[3] = acc_wait + acc_loop + acc_epi;
+    }
+    hl_wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is handed on
+}
+
+template <int TW, bool RELU, bool RES>
+int c64_launch(const HaloParams& p, hipStream_t stream) {
+    constexpr int TH = 256 / TW, HROWS = (TH + 2) * (TW + 2), HBYTES = (HROWS + 7) / 8 * 1024;
+    constexpr int lds = 9 * 64 * 128 + 2 * HBYTES + 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (p.h % TH || p.w % TW) return -2205;  // whole pixel blocks only (block-independent addressing)
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_persistent_kernel<TW, RELU, RES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    const int total = p.n * p.tiles_y * p.tiles_x;
+    const int grid = total < 256 ? total : 256;  // one workgroup per CU
+    static const bool want_stamps = [] { const char* e = getenv("VTD_HALO_STAMPS"); return e && e[0] == '1'; }();
+    if (want_stamps) {  // debug: where a workgroup's time goes, summed over its pixel blocks (synchronises!)
+        HaloParams q = p;
+        unsigned long long* dev = nullptr;
+        if (hipMalloc(&dev, (size_t)grid * 32) != hipSuccess) return -2204;
+        q.stamps = dev;
+        hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<TW, RELU, RES>), dim3(grid), dim3(256), lds, stream, q);
+        (void)hipStreamSynchronize(stream);
+        unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 32);
+        (void)hipMemcpy(h, dev, (size_t)grid * 32, hipMemcpyDeviceToHost);
+        double a = 0, b = 0, c = 0;
+        for (int i = 0; i < grid; ++i) { a += (double)h[4 * i + 1]; b += (double)(h[4 * i + 2] - h[4 * i + 1]); c += (double)(h[4 * i + 3] - h[4 * i + 2]); }
+        const double blocks = (double)total / grid;
+        fprintf(stderr, "[c64 stamps] res=%d blocks/WG %.1f: per block ticks: issue+wait %.1f  K-loop %.1f  epilogue %.1f\n", (int)RES, blocks,
+                a / grid / blocks, b / grid / blocks, c / grid / blocks);
+        free(h);
+        (void)hipFree(dev);
+        return 0;
+    }
+    hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<TW, RELU, RES>), dim3(grid), dim3(256), lds, stream, p);
+    return -(int)hipGetLastError();
+}
+
+template <int TW>
+int c64_dispatch(const HaloParams& p, hipStream_t stream) {
+    if (p.relu) return p.res ? c64_launch<TW, true, true>(p, stream) : c64_launch<TW, true, false>(p, stream);
+    return p.res ? c64_launch<TW, false, true>(p, stream) : c64_launch<TW, false, false>(p, stream);
+}
+
 template <int BN, int TW>
 int halo_launch(const HaloParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW, HROWS = (TH + 2) * (TW + 2), HBYTES = (HROWS + 7) / 8 * 1024;
@@ -276,6 +507,11 @@ bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out) {
     return true;
 }
 
+// The persistent resident-weight variant (bn = 1 in vtd_launch_conv_halo): 64 -> 64 channels, whole pixel blocks.
+bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw) {
+    return c.in_c == 64 && c.cout == 64 && c.wo % tw == 0 && c.ho % (256 / tw) == 0;
+}
+
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream) {
     HaloParams p;
     p.in = c.in; p.wgt = c.wgt; p.bias = c.bias; p.res = (c.flags & EPI_RESIDUAL) ? c.res : nullptr; p.out = (half_t*)c.out;
@@ -288,7 +524,12 @@ int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream
     if (c.in_y0 != c.in_x0 || c.K != 9 * c.in_c || c.out_c != c.cout || p.n <= 0) return -2201;
     if ((int64_t)p.n * c.in_hp * c.in_wp * c.in_c >= (1ll << 31)) return -2202;  // 32-bit element offsets in the loader
     const int th = 256 / tw;
-    p.tiles_x = (p.w + tw - 1) / tw; p.tiles_y = (p.h + th - 1) / th; p.tiles_n = p.cout / bn;
+    p.tiles_x = (p.w + tw - 1) / tw; p.tiles_y = (p.h + th - 1) / th; p.tiles_n = bn > 1 ? p.cout / bn : 1;
+    if (bn == 1) {  // persistent resident-weight variant (cin = cout = 64)
+        if (p.cin != 64 || p.cout != 64) return -2201;
+        p.tiles_n = 1;
+        return tw == 16 ? c64_dispatch<16>(p, stream) : c64_dispatch<32>(p, stream);
+    }
     if (bn == 64 && tw == 16) return halo_launch<64, 16>(p, stream);
     if (bn == 64 && tw == 32) return halo_launch<64, 32>(p, stream);
     if (bn == 128 && tw == 16) return halo_launch<128, 16>(p, stream);

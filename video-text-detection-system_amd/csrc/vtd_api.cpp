@@ -26,6 +26,7 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
+bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
 void vtd_head_tail_pack_w1(const half_t* w1_gemm, half_t* packed);
 void vtd_head_tail_pack_w2(const float* w2, half_t* packed);
@@ -144,6 +145,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
 
 // Tile "configuration" kHaloCfg selects the halo-tile kernel (conv_halo.hip) instead of an implicit-GEMM tile shape.
 static const int kHaloCfg = 100;
+static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 64 -> 64 channels
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
     return !(e && e[0] == '0');
@@ -153,10 +155,10 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
-    if (cfg == kHaloCfg) {
+    if (cfg == kHaloCfg || cfg == kHaloC64Cfg) {
         int bn = 0, tw = 0;
         if (!vtd_conv_halo_supported(p, &bn, &tw)) return ERR_GEOMETRY;
-        return vtd_launch_conv_halo(p, bn, tw, s);
+        return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : bn, tw, s);
     }
     return vtd_launch_conv(p, cfg, s);
 }
@@ -184,16 +186,19 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     }
     int hbn = 0, htw = 0;
     if (!rc && halo_enabled() && vtd_conv_halo_supported(p, &hbn, &htw)) {
-        const char* force = std::getenv("VTD_FORCE_HALO");  // tests: take the halo kernel wherever it applies
-        if (force && force[0] == '1') best = 1e30f;
-        if (!(rc = vtd_launch_conv_halo(p, hbn, htw, s))) {
+        const char* force = std::getenv("VTD_FORCE_HALO");  // tests: 1 = take the halo kernel wherever it applies,
+        if (force && (force[0] == '1' || force[0] == '2')) best = 1e30f;  // 2 = and its persistent 64->64 variant
+        for (int variant = 0; variant < 2 && !rc; ++variant) {
+            if (variant == 1 && !vtd_conv_halo_c64_supported(p, htw)) break;
+            const int bn = variant ? 1 : hbn;
+            if ((rc = vtd_launch_conv_halo(p, bn, htw, s))) break;
             (void)hipEventRecord(e0, s);
-            for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_conv_halo(p, hbn, htw, s);
+            for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_conv_halo(p, bn, htw, s);
             (void)hipEventRecord(e1, s);
             if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            if (!rc && ms < best) { best = ms; best_id = kHaloCfg; }
+            if (!rc && (ms < best || (variant && force && force[0] == '2'))) { best = ms; best_id = variant ? kHaloC64Cfg : kHaloCfg; }
         }
     }
     (void)hipEventDestroy(e0);
@@ -1135,8 +1140,9 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                                       "64,256,s2", "128,64,s2,classed", "128,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        if (cfg == kHaloCfg)
-            std::snprintf(name, name_cap, "conv_halo 3x3 M/img=%d N=%d K=%d", c.ho * c.wo, c.cout, c.K);
+        if (cfg == kHaloCfg || cfg == kHaloC64Cfg)
+            std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : "", c.ho * c.wo,
+                          c.cout, c.K);
         else
             std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 10) ? kTile[cfg] : "default",
                           c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
