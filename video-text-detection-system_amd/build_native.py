@@ -11,6 +11,7 @@ OUT = os.path.join(OUT_DIR, "libvtd_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("VTD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DVTD_CONV_EXPERIMENT (tools/conv_experiment.sh)
 # the post-process geometry replays float32 arithmetic in a fixed order: no fused multiply-add there
 PER_FILE = {"postprocess.hip": ["-ffp-contract=off"]}
 

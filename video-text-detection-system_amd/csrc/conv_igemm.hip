@@ -115,10 +115,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // One LDS-DMA instruction (1 KB) of K-step `ks` into buffer `buf`: j < A_INST feeds the A tile, the rest the B tile.
     auto issue_load = [&](int j, int ks, int buf) {
         char* abase = smem + buf * STAGE;
+#ifdef VTD_CONV_EXPERIMENT  // timing-only variants (tools/conv_experiment.sh): results are garbage, durations are the point
         if (p.dbg >= 3) return;
+        if (p.dbg == 2 && j < A_INST) return;
+#endif
         if (j < A_INST) {
-            if (p.dbg == 2) return;
+#ifdef VTD_CONV_EXPERIMENT
             const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + (p.dbg == 1 ? 0 : kb);
+#else
+            const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + kb;
+#endif
             __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (j * NW + w) * 1024), 16, 0, 0);
         } else {
             const int i = j - A_INST;

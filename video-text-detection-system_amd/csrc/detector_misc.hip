@@ -113,6 +113,153 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
     }
 }
 
+// Fast path of K1 for the common tap counts (720p: 5 x 5 taps, 1080p: 7 x 5).  Same integer arithmetic, same results; what
+// changes is how the bytes move:
+//   * raw BGR rows are widened to one dword per pixel (B | G<<8 | R<<16) while they are staged in LDS, and the horizontally
+//     resampled rows are kept in that form too: a tap is ONE aligned LDS read for all three channels instead of three
+//     byte reads (the old kernel was bound by LDS / TA instruction issue: 15 byte reads + 7 table loads per output pixel);
+//   * a thread owns fixed output columns (t, t+256, t+512) for the whole horizontal pass, so its tap tables live in
+//     registers; taps past a window's end carry zero weights (Pillow pads its tables the same way);
+//   * the vertical pass produces 4 neighbouring pixels per thread: one 16-byte LDS read per tap, one 32-byte store.
+template <int KSX, int KSY>
+__global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // [max_rows][640] dwords (resampled rows) | PRE_CHUNK x [W + KSX] dwords (raw rows, widened) | 16 x (2 + KSY) ints (row taps)
+    uint32_t* const rows = (uint32_t*)lds;
+    const int raw_pitch = p.W + KSX;
+    uint32_t* const raw = rows + p.max_rows * PRE_OUT;
+    int* const ytab = (int*)(raw + PRE_CHUNK * raw_pitch);
+    const int oy0 = blockIdx.x * PRE_TY;
+    const int img = blockIdx.y;
+    const int y_first = p.yb[2 * oy0];
+    const int oy_last = min(oy0 + PRE_TY, PRE_OUT) - 1;
+    const int y_end = p.yb[2 * oy_last] + p.yb[2 * oy_last + 1];
+    const int nrows = y_end - y_first;
+    const int row_bytes = p.W * 3;
+    const uint8_t* src = p.frames + (int64_t)img * p.H * row_bytes;
+    const int tid = threadIdx.x;
+
+    // this thread's output columns and their horizontal taps
+    int xmin[3], kx[3][KSX];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int ox = min(tid + 256 * s, PRE_OUT - 1);
+        xmin[s] = p.xb[2 * ox];
+#pragma unroll
+        for (int t = 0; t < KSX; ++t) kx[s][t] = p.xk[ox * KSX + t];
+    }
+    for (int i = tid; i < PRE_TY * (2 + KSY); i += 256) {
+        const int ty = i / (2 + KSY), e = i - ty * (2 + KSY);
+        const int oy = min(oy0 + ty, PRE_OUT - 1);
+        ytab[i] = e < 2 ? p.yb[2 * oy + e] : p.yk[oy * KSY + (e - 2)];
+    }
+    // zero the KSX padding pixels behind every raw row once (read with zero weights only, but they must be defined)
+    for (int i = tid; i < PRE_CHUNK * KSX; i += 256) raw[(i / KSX) * raw_pitch + p.W + (i % KSX)] = 0u;
+
+    const int quads = p.W >> 2;  // 4 pixels = 12 bytes = 3 dwords (W % 4 == 0 on this path)
+    // raw rows travel HBM -> registers -> LDS; the registers of chunk c+1 are loaded before chunk c is resampled, so the
+    // memory latency (~2 us) hides behind the horizontal taps instead of being paid once per chunk
+    constexpr int MAXIT = 8;  // PRE_CHUNK * (W / 4) / 256 <= 8  <=>  W <= 2048 (checked by the launcher)
+    uint32_t stg[MAXIT][3];
+    auto fetch = [&](int r0) {
+        const int nr = min(PRE_CHUNK, nrows - r0);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < nr * quads) {
+                const int rr = i / quads, q = i - rr * quads;
+                const uint32_t* g = (const uint32_t*)(src + (int64_t)(y_first + r0 + rr) * row_bytes) + q * 3;
+                stg[it][0] = g[0]; stg[it][1] = g[1]; stg[it][2] = g[2];
+            }
+        }
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < nrows; r0 += PRE_CHUNK) {
+        const int nr = min(PRE_CHUNK, nrows - r0);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < nr * quads) {
+                const int rr = i / quads, q = i - rr * quads;
+                const uint32_t d0 = stg[it][0], d1 = stg[it][1], d2 = stg[it][2];
+                uint4 px;
+                px.x = d0 & 0xffffffu;
+                px.y = ((d0 >> 24) | (d1 << 8)) & 0xffffffu;
+                px.z = ((d1 >> 16) | (d2 << 16)) & 0xffffffu;
+                px.w = d2 >> 8;
+                *(uint4*)(raw + rr * raw_pitch + q * 4) = px;
+            }
+        }
+        __syncthreads();
+        if (r0 + PRE_CHUNK < nrows) fetch(r0 + PRE_CHUNK);
+        for (int rr = 0; rr < nr; ++rr) {
+            const uint32_t* row = raw + rr * raw_pitch;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ox = tid + 256 * s;
+                if (ox < PRE_OUT) {
+                    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+#pragma unroll
+                    for (int t = 0; t < KSX; ++t) {
+                        const uint32_t px = row[xmin[s] + t];
+                        s0 += (int)(px & 0xffu) * kx[s][t];
+                        s1 += (int)((px >> 8) & 0xffu) * kx[s][t];
+                        s2 += (int)(px >> 16) * kx[s][t];
+                    }
+                    rows[(r0 + rr) * PRE_OUT + ox] = (uint32_t)clip8_22(s0) | ((uint32_t)clip8_22(s1) << 8) | ((uint32_t)clip8_22(s2) << 16);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // vertical taps + normalise, 4 pixels per thread; input channel order is BGR, output RGB0
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int idx = tid; idx < PRE_TY * (PRE_OUT / 4); idx += 256) {
+        const int ty = idx / (PRE_OUT / 4), g = idx - ty * (PRE_OUT / 4);
+        const int oy = oy0 + ty;
+        if (oy >= PRE_OUT) break;
+        const int* yt = ytab + ty * (2 + KSY);
+        const int ymin = yt[0] - y_first;
+        int acc[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[q][c] = 1 << 21;
+#pragma unroll
+        for (int t = 0; t < KSY; ++t) {
+            const int kv = yt[2 + t];
+            // rows past the window carry kv == 0; clamp the row index so the read stays inside the buffer
+            const int r = min(ymin + t, nrows - 1);
+            const uint4 px = *(const uint4*)(rows + r * PRE_OUT + g * 4);
+            const uint32_t pv[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q][0] += (int)(pv[q] & 0xffu) * kv;
+                acc[q][1] += (int)((pv[q] >> 8) & 0xffu) * kv;
+                acc[q][2] += (int)(pv[q] >> 16) * kv;
+            }
+        }
+        half8 o01, o23;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float b = (float)clip8_22(acc[q][0]), gch = (float)clip8_22(acc[q][1]), r = (float)clip8_22(acc[q][2]);
+            const half_t h0 = (half_t)((r / 255.0f - mean[0]) / stdv[0]);
+            const half_t h1 = (half_t)((gch / 255.0f - mean[1]) / stdv[1]);
+            const half_t h2 = (half_t)((b / 255.0f - mean[2]) / stdv[2]);
+            if (q < 2) { o01[q * 4] = h0; o01[q * 4 + 1] = h1; o01[q * 4 + 2] = h2; o01[q * 4 + 3] = (half_t)0.f; }
+            else { o23[(q - 2) * 4] = h0; o23[(q - 2) * 4 + 1] = h1; o23[(q - 2) * 4 + 2] = h2; o23[(q - 2) * 4 + 3] = (half_t)0.f; }
+        }
+        // pixel (oy+3, 4g+3) of the ring-3 row: 8-byte aligned only, so two 8-byte-aligned 16-byte halves are not guaranteed
+        half_t* dst = p.out + (((int64_t)img * 646 + oy + 3) * 646 + g * 4 + 3) * 4;
+        *(half4*)(dst) = half4{o01[0], o01[1], o01[2], o01[3]};
+        *(half4*)(dst + 4) = half4{o01[4], o01[5], o01[6], o01[7]};
+        *(half4*)(dst + 8) = half4{o23[0], o23[1], o23[2], o23[3]};
+        *(half4*)(dst + 12) = half4{o23[4], o23[5], o23[6], o23[7]};
+    }
+}
+
 // Reference-format network input ([n,3,640,640] float32, already normalised) -> ring-3 NHWC4 fp16.
 __global__ void nchw_to_input_kernel(const float* __restrict__ x, half_t* __restrict__ out, int n) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,6 +362,26 @@ __global__ __launch_bounds__(256) void final_convt_sigmoid_kernel(const FinalPar
 int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
                           const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream) {
     PreParams p{frames, out, xb, xk, yb, yk, H, W, ksx, ksy, max_rows};
+    if ((W & 3) == 0 && W <= 2048 && ksy == 5 && (ksx == 5 || ksx == 7)) {  // 720p / 1080p class sizes: the widened-pixel fast path
+        const int lds_fast = (max_rows * PRE_OUT + PRE_CHUNK * (W + ksx) + PRE_TY * (2 + ksy)) * 4;
+        if (lds_fast <= 160 * 1024) {
+            static bool attr5 = false, attr7 = false;
+            if (ksx == 5) {
+                if (!attr5) {
+                    VTD_HIP_CHECK(hipFuncSetAttribute((const void*)preprocess_fast_kernel<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr5 = true;
+                }
+                hipLaunchKernelGGL((preprocess_fast_kernel<5, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(256), lds_fast, stream, p);
+            } else {
+                if (!attr7) {
+                    VTD_HIP_CHECK(hipFuncSetAttribute((const void*)preprocess_fast_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr7 = true;
+                }
+                hipLaunchKernelGGL((preprocess_fast_kernel<7, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(256), lds_fast, stream, p);
+            }
+            return -(int)hipGetLastError();
+        }
+    }
     const int lds = ((max_rows * PRE_OUT * 3 + 15) & ~15) + PRE_CHUNK * ((W * 3 + 15) & ~15);
     if (lds > 160 * 1024) return -1010;
     static bool attr_done = false;
