@@ -124,8 +124,13 @@ def main():
 
     def step():
         rec, cnt = step_full() if args.workload == "full" else step_detector()
-        if world > 1:  # the one exchange step of the path: detection records of every rank to every rank
-            shard.gather_detections(rec, cnt)
+        if world > 1:
+            # the one exchange step of the path: detection records of every rank to every rank.  Enqueued on the stream
+            # that produced them (the detector's post-process side stream), so it is ordered behind the records without
+            # stalling the caller's stream, where the next batch's DBNet is already queued.
+            side = pipe.detector._post_stream()
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+                last["gathered"] = shard.gather_detections(rec, cnt)
         return rec, cnt
 
     def barrier():
