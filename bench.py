@@ -41,6 +41,9 @@ def parse():
                     help="full = BASELINE configs[2] (detect + recognize); detector = configs[1]")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
+    ap.add_argument("--upload", action="store_true",
+                    help="PCIe-inclusive variant (not the headline value): every step uploads its batch from pinned host memory "
+                         "on an upload stream")
     ap.add_argument("--layers-out", default=None, help="write the per-launch table as JSON to this path")
     return ap.parse_args()
 
@@ -69,6 +72,9 @@ def main():
     B, H, W = args.batch, args.height, args.width
     frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
     dev_frames = DeviceFrames(frames)
+    if args.upload:
+        host_frames = torch.from_numpy(frames).pin_memory()
+        upload_stream = torch.cuda.Stream()
     sd = weights.margin_detector_state_dict(args.backbone, 0)
     from vtd_amd import nets as mynets
     from vtd_amd import shard
@@ -85,10 +91,13 @@ def main():
 
     inflight = {"det": None, "rec": None}
 
+    def next_batch():
+        return DeviceFrames(host_frames, stream=upload_stream) if args.upload else dev_frames
+
     def step_detector():
         # the product's detector half, two batches in flight: enqueue batch i (preprocess -> DBNet on the caller's stream,
         # post-process + record copy on the side stream), then turn the records of batch i-1 into the result dicts
-        t = pipe.detector.submit_batch(dev_frames, 0.5)
+        t = pipe.detector.submit_batch(next_batch(), 0.5)
         if inflight["det"] is not None:
             last["detections"] = pipe.detector.finish_batch(inflight["det"])
         inflight["det"] = t
@@ -103,7 +112,7 @@ def main():
     # detector(i) is enqueued, then the host collects the boxes of batch i-1 and enqueues its recogniser, then builds
     # the result dicts of batch i-2.  Every step retires one whole batch (result dicts included).
     def step_full():
-        job = pipe.submit_detection(dev_frames)
+        job = pipe.submit_detection(next_batch())
         keep = job["det"]["keep"]
         if inflight["rec"] is not None:
             last["results"] = pipe.collect(inflight["rec"])
@@ -254,7 +263,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16",
-            "data": "synthetic",
+            "data": "synthetic" + (" (uploaded from pinned host memory every step: PCIe-inclusive variant)" if args.upload else ""),
             "config": {"workload": (f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), fp16"
                                     if args.workload == "detector" else
                                     f"B={B} {H}p frames, full pipeline: DBNet-{args.backbone} + crop + CRNN + CTC decode -> result dicts, fp16"),

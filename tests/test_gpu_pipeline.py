@@ -94,3 +94,18 @@ def test_pipelined_halves_equal_the_one_shot_pass(pipeline):
     ja = p.submit_recognition(ja)
     jb = p.submit_recognition(jb)
     assert p.collect(ja) == exp_a and p.collect(jb) == exp_b
+
+
+def test_upload_stream_batches_equal_resident_batches(pipeline):
+    """Frames uploaded from pinned host memory on their own stream (DeviceFrames(stream=...)): the detector, its side-stream
+    post-process and the recogniser order themselves behind the upload event; results equal the resident-batch pass, with
+    several uploads in flight."""
+    import torch
+    from vtd_amd.engine import DeviceFrames
+    p, _, _ = pipeline
+    up = torch.cuda.Stream()
+    host = [torch.from_numpy(np.stack([synth.text_frame(300 + 10 * k + i)[0] for i in range(3)])).pin_memory() for k in range(3)]
+    exp = [p.process_device_batch(DeviceFrames(h.numpy())) for h in host]
+    jobs = [p.submit_detection(DeviceFrames(h, stream=up)) for h in host]   # three uploads + detector passes enqueued
+    jobs = [p.submit_recognition(j) for j in jobs]
+    assert [p.collect(j) for j in jobs] == exp

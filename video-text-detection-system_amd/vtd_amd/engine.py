@@ -45,7 +45,9 @@ PINNED = PinnedPool()
 class DeviceFrames:
     """A batch of equally sized uint8 BGR HWC frames resident in HBM ([n,H,W,3] cuda tensor)."""
 
-    def __init__(self, frames):
+    def __init__(self, frames, stream=None):
+        """`stream`: upload on that HIP stream (give it pinned host memory and the copy overlaps the previous batch's
+        compute); consumers order themselves behind `self.ready`.  Default: the caller's current stream."""
         if isinstance(frames, np.ndarray):
             frames = torch.from_numpy(np.ascontiguousarray(frames))
         elif isinstance(frames, (list, tuple)):
@@ -54,7 +56,19 @@ class DeviceFrames:
             frames = frames.unsqueeze(0)
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
             raise ValueError("frames must be uint8 [n,H,W,3] (BGR)")
-        self.tensor = frames.to("cuda", non_blocking=True).contiguous()
+        self.ready = None
+        if stream is None or frames.is_cuda:
+            self.tensor = frames.to("cuda", non_blocking=True).contiguous()
+        else:
+            with torch.cuda.stream(stream):
+                self.tensor = frames.contiguous().to("cuda", non_blocking=True)
+                self.ready = torch.cuda.Event()
+                self.ready.record()
+
+    def wait_ready(self):
+        """Make the current stream wait for an upload that was issued on another stream (no-op otherwise)."""
+        if self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
 
     @property
     def n(self):
@@ -112,6 +126,7 @@ class DetectorEngine:
     def _set_input(self, x):
         if isinstance(x, DeviceFrames):
             n = x.n
+            x.wait_ready()
             _native.check(self.lib.vtd_detector_preprocess(self.handle, C.c_void_p(x.tensor.data_ptr()), n, x.height, x.width,
                                                            _stream_ptr()), "vtd_detector_preprocess")
             return n, x
@@ -292,6 +307,7 @@ class RecognizerEngine:
         b = boxes if torch.is_tensor(boxes) else torch.as_tensor(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
         b = b.to("cuda", torch.int32).contiguous()
         n = b.shape[0]
+        frames.wait_ready()
         _native.check(self.lib.vtd_recognizer_crop_resize(self.handle, C.c_void_p(frames.tensor.data_ptr()), frames.n, frames.height,
                                                           frames.width, C.c_void_p(b.data_ptr()), n, _stream_ptr()),
                       "vtd_recognizer_crop_resize")
