@@ -129,6 +129,31 @@ def test_dbnet_fused_stem_pool(r18, r18_fused):
         eng_f.read_tap("stem", 1)  # never materialised
 
 
+@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 102])
+def test_composed_head_entry_every_tile_configuration(hip, monkeypatch, cfg):
+    """The composed conv on each of its tile configurations (128- and 256-row pixel-list tiles, 2 / 3 LDS stages): same
+    probabilities as the fp32 oracle, borders included (the per-class padding rows of the two list cuts differ)."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    monkeypatch.setenv("VTD_FORCE_CLASSED_CFG", str(cfg))
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(31))
+    ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
+    h1_ref = torch.relu(onets._bn(torch.nn.functional.conv2d(ref["p2"], sd["head.probability_head.0.weight"],
+                                                             sd["head.probability_head.0.bias"], 1, 1), sd, "head.probability_head.1")).numpy()
+    eng = DetectorEngine("resnet18", sd, max_batch=2)
+    try:
+        prob = eng.forward(x)["probability"].cpu().numpy()
+        h1 = eng.read_tap("head1", 2)
+        names = [r[0] for r in detector_profile(eng)]
+    finally:
+        eng.close()
+    want = {8: "128,64,s2,classed", 9: "128,64,s3,classed", 10: "256,64,s2,classed", 11: "256,64,s3,classed",
+            102: "head_entry_halo"}[cfg]  # 102: interior classes on the halo-plane kernel, border classes on 128-row tiles
+    assert any(want in n for n in names), names
+    assert _rel(h1, h1_ref) < 1.5e-2
+    assert float(np.abs(prob - ref["probability"].numpy()).max()) <= 2e-3
+
+
 def test_dbnet_halo_conv_forced(hip, monkeypatch):
     """conv_halo.hip (3x3 stride-1 layers with the input halo staged once in LDS) forced wherever it applies -- 160x160,
     80x80 and 40x40 (partial 16x16 pixel blocks) maps, with and without residual: taps and probabilities against the fp32

@@ -1,0 +1,46 @@
+// Sustained dense-fp16 MFMA rate and shader clock of the GPU this runs on: a bare v_mfma_f32_16x16x32_f16 loop
+// (operands in registers, 4 independent accumulator chains per wave, W waves per SIMD) timed with HIP events and
+// with s_memtime.  Build + run:  hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__global__ void mfma_loop(int iters, float* out, unsigned long long* cyc) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); }
+    floatx4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+int main() {
+    const int iters = 200000;
+    for (int waves_per_simd = 1; waves_per_simd <= 2; ++waves_per_simd) {
+        const int blocks = 256, threads = 256 * waves_per_simd;  // one block per CU
+        float* out; unsigned long long* cyc;
+        hipMalloc(&out, blocks * threads * 4); hipMalloc(&cyc, blocks * 8);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        mfma_loop<<<blocks, threads>>>(1000, out, cyc);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        mfma_loop<<<blocks, threads>>>(iters, out, cyc);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+        double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
+        const double flops = (double)blocks * (threads / 64) * iters * 4.0 * 16 * 16 * 32 * 2;
+        printf("waves/SIMD %d: %.3f ms, %.1f TFLOP/s dense fp16; s_memtime ticks per wave %.0f -> %.3f ticks/ns; MFMA issue interval %.2f ticks\n",
+               waves_per_simd, ms, flops / (ms * 1e-3) / 1e12, avg, avg / (ms * 1e6), avg / (iters * 4.0 * waves_per_simd));
+    }
+    return 0;
+}

@@ -7,9 +7,10 @@
 // not LDS reads -- is what bounds the layers with few output channels.  Here a workgroup owns a TH x TW block of output
 // pixels (256 GEMM rows) and stages the (TH+2) x (TW+2) input halo of one 64-channel chunk ONCE; the nine taps are nine
 // K-steps that read the same LDS image at shifted rows.  Per K-step only the weights (BN x 128 bytes) still stream in.
-//   * LDS image of the halo: one 128-byte row per pixel, 16-byte chunks XOR-swizzled by ((row >> 1) & 7) on the source
-//     side of the LDS-DMA, so a 16-lane ds_read_b128 group reading 16 consecutive pixels is conflict-free for even
-//     tap shifts and 2-way for odd ones;
+//   * LDS image of the halo: one 128-byte row per pixel, 16-byte chunks XOR-swizzled by (row & 6) on the source side of
+//     the LDS-DMA: with that pattern a ds_read_b128 of 16 CONSECUTIVE halo rows starting at ANY row is conflict-free in all
+//     four hardware lane groups (brute-forced over the linear swizzles; the ((row >> 1) & 7) pattern of the aligned
+//     tiles in conv_igemm.hip is 2-way to 4-way for starts that are not multiples of 4, i.e. for most tap shifts);
 //   * weights: 3-stage ring filled by LDS-DMA, counted vmcnt + one s_barrier per K-step (as conv_igemm.hip);
 //     the halo of the next channel chunk is fetched piecewise during the current chunk's K-steps;
 //   * waves: 4 x (BN/64), each a 64 x 64 sub-tile (16 accumulator fragments), v_mfma_f32_16x16x32_f16, weights as the first
@@ -80,7 +81,7 @@ __global__ __launch_bounds__((BN / 64) * 256) void conv_halo_kernel(const HaloPa
         int gy = y0 - 1 + hy + p.in_ring, gx = x0 - 1 + hx + p.in_ring;
         gy = gy < p.in_hp ? gy : p.in_hp - 1;  // partial tiles: stay inside the allocation (those outputs are masked)
         gx = gx < p.in_wp ? gx : p.in_wp - 1;
-        const int c_log = (lane & 7) ^ ((row >> 1) & 7);
+        const int c_log = (lane & 7) ^ (row & 6);
         hoff[k] = ((img * p.in_hp + gy) * p.in_wp + gx) * p.cin + c_log * 8;
     }
     auto issue_halo = [&](int k, int chunk, int buf) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__((BN / 64) * 256) void conv_halo_kernel(const HaloPa
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int hrow = hbase[j] + tapoff;
-                    af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ ((hrow >> 1) & 7)) << 4));
+                    af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ (hrow & 6)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + (((fq + 4 * kk) ^ bswz) << 4));
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_persistent_kernel(const Ha
         int row = piece * 8 + lrow;
         row = row < HROWS ? row : HROWS - 1;
         const int hy = row / HWD, hx = row - hy * HWD;
-        hrel[k] = (hy * p.in_wp + hx) * 64 + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        hrel[k] = (hy * p.in_wp + hx) * 64 + ((lane & 7) ^ (row & 6)) * 8;
         hdst[k] = piece < HPIECES ? WBYTES + piece * 1024 : WBYTES + 2 * HBYTES;
     }
     auto issue_halo = [&](int img, int y0, int x0, int buf) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_persistent_kernel(const Ha
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int hrow = hbase[j] + tapoff;
-                af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ ((hrow >> 1) & 7)) << 4));
+                af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ (hrow & 6)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(wl + tap * 8192 + (i * 16 + fr) * 128 + (((fq + 4 * kk) ^ bswz) << 4));

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
 int launch_cfg(const ConvParams& p, hipStream_t stream) {
-    const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;
+    const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;  // (classed: vtd_launch_conv set M for this tile height)
     const int tiles_n = p.cout_pad / BN;
     constexpr int stage_bytes = STAGES * (BM + BN) * 128;
     constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
@@ -436,12 +436,13 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //   5   128x64    4     2        48 KB   3      short-K / store-bound layers: more blocks in flight per CU
 //   6   128x64    4     3        72 KB   2
 //   7   64x256    4     2        80 KB   2      only for the fused DB-head tail (EPI_HEAD_FINAL needs all 256 columns)
-//   8/9 128x64    4     2/3               only for the classed dual-source op (pixel-list tiles are 128 rows)
-int vtd_conv_num_configs() { return 10; }
+//   8/9   128x64  4     2/3               only for the classed dual-source op (pixel-list tiles of 128 rows)
+//   10/11 256x64  4     2/3               same op, pixel lists cut into 256-row tiles: 17 % fewer LDS-DMA pieces per FLOP
+int vtd_conv_num_configs() { return 12; }
 
 bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
-    if (p.plist) return (cfg == 8 || cfg == 9) && p.cout_pad % 64 == 0;
+    if (p.plist) return ((cfg == 8 || cfg == 9) || ((cfg == 10 || cfg == 11) && p.plist_b && p.tile_combo_b && p.tiles_per_img_b > 0)) && p.cout_pad % 64 == 0;
     switch (cfg) {
         case 0: case 1: case 2: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
@@ -487,6 +488,13 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         case 6: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
         case 7: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
-        default: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
+        case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
+        default: {
+            // 256-row classed tiles: same images, the other cut of the pixel lists
+            const int n_img = p.M / (p.tiles_per_img * 128);
+            p.plist = p.plist_b; p.tile_combo = p.tile_combo_b; p.tiles_per_img = p.tiles_per_img_b;
+            p.M = n_img * p.tiles_per_img_b * 256;
+            return cfg == 10 ? launch_cfg<256, 64, 4, 1, 2, true>(p, stream) : launch_cfg<256, 64, 4, 1, 3, true>(p, stream);
+        }
     }
 }

@@ -25,6 +25,8 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
                        hipStream_t stream);
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
+int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
+int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, hipStream_t stream);
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
 bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
@@ -103,6 +105,13 @@ struct ConvOp {
     // classed dual-source mode (fused FPN top + head entry)
     const uint32_t* plist = nullptr;
     const int* tile_combo = nullptr;
+    const uint32_t* plist_b = nullptr;  // 256-row cut of the pixel lists
+    const int* tile_combo_border = nullptr;  // the 12 border classes only (interior classes run on head_entry_halo.hip)
+    int tiles_border = 0;
+    const int* he_steps = nullptr;  // step tables of the four interior classes
+    int he_nsteps = 0;
+    const int* tile_combo_b = nullptr;
+    int tiles_per_img_b = 0;
     int tiles_per_img = 0, seg1_steps = 0, cin_steps2 = 0, kw2 = 0, s_step2 = 0, r_step2 = 0, img_h = 0, img_w = 0;
     TensorDesc in2;
     const float* bias_tab = nullptr;
@@ -136,6 +145,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     p.head_w = c.head_w; p.head_b = c.head_b; p.prob_out = (float*)c.out_f32;
     if (c.plist) {
         p.plist = c.plist; p.tile_combo = c.tile_combo; p.tiles_per_img = c.tiles_per_img;
+        p.plist_b = c.plist_b; p.tile_combo_b = c.tile_combo_b; p.tiles_per_img_b = c.tiles_per_img_b;
         p.in2 = c.in2.ptr; p.in2_hp = c.in2.hp; p.in2_wp = c.in2.wp; p.in2_c = c.in2.c; p.in2_ring = c.in2.ring;
         p.seg1_steps = c.seg1_steps; p.cin_steps2 = c.cin_steps2; p.kw2 = c.kw2; p.s_step2 = c.s_step2; p.r_step2 = c.r_step2;
         p.bias_tab = c.bias_tab; p.img_h = c.img_h; p.img_w = c.img_w;
@@ -146,6 +156,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
 // Tile "configuration" kHaloCfg selects the halo-tile kernel (conv_halo.hip) instead of an implicit-GEMM tile shape.
 static const int kHaloCfg = 100;
 static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 64 -> 64 channels
+static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
     return !(e && e[0] == '0');
@@ -155,6 +166,15 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
+    if (cfg == kHeadEntryHaloCfg) {
+        if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
+        int rc = vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, s);
+        if (rc) return rc;
+        ConvParams pb = p;  // border pixels: the same op restricted to the border classes' tiles
+        pb.tile_combo = c.tile_combo_border; pb.tiles_per_img = c.tiles_border; pb.M = n * c.tiles_border * 128;
+        pb.plist_b = nullptr; pb.tile_combo_b = nullptr; pb.tiles_per_img_b = 0;
+        return vtd_launch_conv(pb, 8, s);
+    }
     if (cfg == kHaloCfg || cfg == kHaloC64Cfg) {
         int bn = 0, tw = 0;
         if (!vtd_conv_halo_supported(p, &bn, &tw)) return ERR_GEOMETRY;
@@ -173,6 +193,15 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     VTD_HIP_CHECK(hipEventCreate(&e1));
     float best = 1e30f;
     int best_id = -1, rc = 0;
+    if (p.plist) {  // tests: pin the composed conv to one tile configuration (8..11)
+        const char* fc = std::getenv("VTD_FORCE_CLASSED_CFG");
+        if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || (std::atoi(fc) == kHeadEntryHaloCfg && c.he_steps))) {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *best_cfg = std::atoi(fc);
+            return 0;
+        }
+    }
     for (int cfg = 0; cfg < vtd_conv_num_configs() && !rc; ++cfg) {
         if (!vtd_conv_config_valid(p, cfg)) continue;
         if ((rc = vtd_launch_conv(p, cfg, s))) break;  // warm-up (also sets the LDS attribute)
@@ -183,6 +212,17 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; best_id = cfg; }
+    }
+    if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernel + border tiles
+        if (!(rc = launch_conv_op(c, n, s, kHeadEntryHaloCfg))) {
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch_conv_op(c, n, s, kHeadEntryHaloCfg);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (!rc && ms < best) { best = ms; best_id = kHeadEntryHaloCfg; }
+        }
     }
     int hbn = 0, htw = 0;
     if (!rc && halo_enabled() && vtd_conv_halo_supported(p, &hbn, &htw)) {
@@ -607,7 +647,7 @@ static int compose_head_entry(const ModelBase* d, const std::string& hp, int c2c
 // `tile_combo` then lists the tiles in EXECUTION order as (weight class | pixel-list chunk << 8): the four parity classes
 // of the image interior are interleaved chunk by chunk, so the tiles that gather the same rows of C2 / L3 run back to
 // back on one XCD and its L2 serves the 4x overlap (class-major order re-streamed the whole image once per class).
-static void build_pixel_list(int h, int w, std::vector<uint32_t>& plist, std::vector<int>& tile_combo) {
+static void build_pixel_list(int h, int w, int bm, std::vector<uint32_t>& plist, std::vector<int>& tile_combo) {
     auto kind_values = [](int n, int kind) {
         std::vector<int> v;
         if (kind == 0) v.push_back(0);
@@ -622,11 +662,11 @@ static void build_pixel_list(int h, int w, std::vector<uint32_t>& plist, std::ve
         for (int xk = 0; xk < 4; ++xk) {
             const std::vector<int> ys = kind_values(h, yk), xs = kind_values(w, xk);
             size_t cnt = 0;
-            const size_t first_chunk = plist.size() / 128;
+            const size_t first_chunk = plist.size() / bm;
             for (int y : ys)
                 for (int x : xs) { plist.push_back((uint32_t)y | ((uint32_t)x << 16)); ++cnt; }
-            while (cnt % 128) { plist.push_back(0xffffffffu); ++cnt; }
-            for (size_t t = 0; t < cnt / 128; ++t) chunks[yk * 4 + xk].push_back((int)(first_chunk + t));
+            while (cnt % bm) { plist.push_back(0xffffffffu); ++cnt; }
+            for (size_t t = 0; t < cnt / bm; ++t) chunks[yk * 4 + xk].push_back((int)(first_chunk + t));
         }
     const int interior[4] = {1 * 4 + 1, 1 * 4 + 2, 2 * 4 + 1, 2 * 4 + 2};  // (mid even|odd rows) x (mid even|odd columns)
     size_t longest = 0;
@@ -652,12 +692,36 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
     if (rc) return rc;
     std::vector<uint32_t> plist;
     std::vector<int> tile_combo;
-    build_pixel_list(c2.h, c2.w, plist, tile_combo);
-    void *pl = nullptr, *tc = nullptr, *bt = nullptr;
+    build_pixel_list(c2.h, c2.w, 128, plist, tile_combo);
+    std::vector<uint32_t> plist_b;
+    std::vector<int> tile_combo_b;
+    build_pixel_list(c2.h, c2.w, 256, plist_b, tile_combo_b);
+    void *pl = nullptr, *tc = nullptr, *bt = nullptr, *plb = nullptr, *tcb = nullptr;
+    if ((rc = upload(d->arena, plist_b.data(), plist_b.size() * sizeof(uint32_t), &plb))) return rc;
+    if ((rc = upload(d->arena, tile_combo_b.data(), tile_combo_b.size() * sizeof(int), &tcb))) return rc;
+    op.plist_b = (const uint32_t*)plb;
+    op.tile_combo_b = (const int*)tcb;
+    op.tiles_per_img_b = (int)tile_combo_b.size();
     if ((rc = upload(d->arena, ce.w.data(), ce.w.size() * sizeof(half_t), (void**)&op.w))) return rc;
     if ((rc = upload(d->arena, ce.bias.data(), ce.bias.size() * sizeof(float), &bt))) return rc;
     if ((rc = upload(d->arena, plist.data(), plist.size() * sizeof(uint32_t), &pl))) return rc;
     if ((rc = upload(d->arena, tile_combo.data(), tile_combo.size() * sizeof(int), &tc))) return rc;
+    {   // interior classes on the halo-plane kernel: per-class step tables; border classes keep their 128-row tiles
+        const int nch1 = c2.c / 64, nsteps = 25 * nch1 + 36;
+        std::vector<int> steps((size_t)4 * nsteps * 2);
+        for (int q = 0; q < 4; ++q)
+            if (vtd_head_entry_halo_steps(q >> 1, q & 1, nch1, &steps[(size_t)q * nsteps * 2]) != nsteps) return ERR_GEOMETRY;
+        std::vector<int> border;
+        for (int e : tile_combo) {
+            const int cl = e & 0xff;
+            if (cl != 5 && cl != 6 && cl != 9 && cl != 10) border.push_back(e);
+        }
+        void *st = nullptr, *bd = nullptr;
+        if ((rc = upload(d->arena, steps.data(), steps.size() * sizeof(int), &st))) return rc;
+        if ((rc = upload(d->arena, border.data(), border.size() * sizeof(int), &bd))) return rc;
+        op.he_steps = (const int*)st; op.he_nsteps = nsteps;
+        op.tile_combo_border = (const int*)bd; op.tiles_border = (int)border.size();
+    }
     op.bias = (float*)bt;  // first class doubles as the (unused) flat bias
     op.bias_tab = (const float*)bt;
     op.plist = (const uint32_t*)pl;
@@ -1137,14 +1201,17 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     if (o.kind == Op::CONV) {
         const ConvOp& c = o.conv;
         static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3",
-                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed"};
+                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        if (cfg == kHaloCfg || cfg == kHaloC64Cfg)
+        if (cfg == kHeadEntryHaloCfg)
+            std::snprintf(name, name_cap, "head_entry_halo (+ border tiles conv_igemm<128,64,s2,classed>) M/img=%d N=%d K=%d "
+                          "(lateral+smooth+head conv composed)", c.ho * c.wo, c.cout, c.K);
+        else if (cfg == kHaloCfg || cfg == kHaloC64Cfg)
             std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : "", c.ho * c.wo,
                           c.cout, c.K);
         else
-            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 10) ? kTile[cfg] : "default",
+            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 12) ? kTile[cfg] : "default",
                           c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);

@@ -64,6 +64,9 @@ struct ConvParams {
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
     const int* tile_combo;   // per tile in execution order: weight class | pixel-list chunk << 8
+    const uint32_t* plist_b; // the same lists cut into 256-row tiles (configurations 10 / 11)
+    const int* tile_combo_b;
+    int tiles_per_img_b;
     int tiles_per_img;
     const half_t* in2;       // second source (L3): gathered at (y>>1, x>>1) - 1
     int in2_hp, in2_wp, in2_c, in2_ring;
