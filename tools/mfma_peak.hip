@@ -6,6 +6,45 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+template <int CH>
+__global__ void mfma_chains(int iters, float* out, unsigned long long* cyc) {
+    half8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); }
+    floatx4 c[CH];
+    for (int k = 0; k < CH; ++k) c[k] = floatx4{0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[k], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float acc = 0;
+    for (int k = 0; k < CH; ++k) acc += c[k][k & 3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int CH>
+void run_chains(int waves_per_simd) {
+    const int iters = 50000, blocks = 256, threads = 256 * waves_per_simd;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, blocks * threads * 4); hipMalloc(&cyc, blocks * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    mfma_chains<CH><<<blocks, threads>>>(100, out, cyc);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    mfma_chains<CH><<<blocks, threads>>>(iters, out, cyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
+    const double flops = (double)blocks * (threads / 64) * iters * (double)CH * 16 * 16 * 32 * 2;
+    printf("chains %2d waves/SIMD %d: %7.1f TFLOP/s; clock %.2f GHz; cycles per MFMA per wave %.1f\n", CH, waves_per_simd,
+           flops / (ms * 1e-3) / 1e12, avg / (ms * 1e6), avg / ((double)iters * CH));
+    hipFree(out); hipFree(cyc);
+}
+
 __global__ void mfma_loop(int iters, float* out, unsigned long long* cyc) {
     half8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); }
@@ -42,5 +81,6 @@ int main() {
         printf("waves/SIMD %d: %.3f ms, %.1f TFLOP/s dense fp16; s_memtime ticks per wave %.0f -> %.3f ticks/ns; MFMA issue interval %.2f ticks\n",
                waves_per_simd, ms, flops / (ms * 1e-3) / 1e12, avg, avg / (ms * 1e6), avg / (iters * 4.0 * waves_per_simd));
     }
+    for (int w = 1; w <= 2; ++w) { run_chains<2>(w); run_chains<8>(w); run_chains<16>(w); }
     return 0;
 }
