@@ -109,3 +109,28 @@ def test_upload_stream_batches_equal_resident_batches(pipeline):
     jobs = [p.submit_detection(DeviceFrames(h, stream=up)) for h in host]   # three uploads + detector passes enqueued
     jobs = [p.submit_recognition(j) for j in jobs]
     assert [p.collect(j) for j in jobs] == exp
+
+
+def test_process_video_pipelined_loop_matches_batch_pass(pipeline, tmp_path):
+    """process_video on a raw-frame source: batches ride the three-deep device pipeline (upload stream, detector,
+    post-process / recogniser streams) and come back in frame order with exactly the results of the one-shot batch pass."""
+    from vtd_amd.engine import DeviceFrames
+    p, _, _ = pipeline
+    frames = np.stack([synth.text_frame(400 + i)[0] for i in range(11)])
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    (tmp_path / "clip.npy.json").write_text(json.dumps({"fps": 10.0}))
+    old_bs = p.batch_size
+    p.batch_size = 4   # 4 + 4 + 3 frames: three batches in flight, the last one short
+    try:
+        out = asyncio.run(p.process_video(str(path), str(tmp_path)))
+    finally:
+        p.batch_size = old_bs
+    assert out["status"] == "success" and len(out["results"]) == 11
+    assert [r["frame_number"] for r in out["results"]] == list(range(11))
+    exp = []
+    for s in range(0, 11, 4):
+        exp += p.process_device_batch(DeviceFrames(frames[s:s + 4]), [(i, i / 10.0) for i in range(s, min(s + 4, 11))])
+    for got, want in zip(out["results"], exp):
+        assert got["detections"] == want["detections"]
+    assert out["summary"]["total_frames"] == 11

@@ -269,14 +269,18 @@ int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int ns
     p.blocks_y = (cnt_y + 7) / 8; p.blocks_x = (cnt_x + 15) / 16;
     if (p.n <= 0 || p.c2_ring < 2 || p.l3_ring < 1) return -2302;
     static const int ring = [] { const char* e = getenv("VTD_HEAD_HALO_RING"); const int r = e ? atoi(e) : 2; return (r == 2 || r == 3) ? r : 2; }();
-    static const int nw = [] { const char* e = getenv("VTD_HEAD_HALO_WAVES"); return (e && atoi(e) == 4) ? 4 : 2; }();
+    static const int nw = [] { const char* e = getenv("VTD_HEAD_HALO_WAVES"); return (e && atoi(e) == 2) ? 2 : 4; }();
     const int lds = HE_HALO_BYTES + ring * HE_BSTAGE + 2 * nsteps * 4;  // halo + weight ring + step table (>= the 34 KB epilogue tile)
     const int grid = p.n * p.blocks_y * p.blocks_x * 4;
     p.stamps = nullptr;
     static const bool want_stamps = [] { const char* e = getenv("VTD_HALO_STAMPS"); return e && e[0] == '1'; }();
+    static bool attr_done = false;  // (ring, nw) are fixed for the life of the process: one instantiation is ever launched
     auto go = [&](auto kernel, int threads) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(int)e;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return -(int)e;
+            attr_done = true;
+        }
         if (want_stamps) {  // debug: where a workgroup's K loop goes (synchronises!)
             unsigned long long* dev = nullptr;
             if (hipMalloc(&dev, (size_t)grid * 32) != hipSuccess) return -2304;

@@ -64,9 +64,19 @@ class VideoTextPipeline:
             total_frames = video_info.get("frame_count", 0)
             pending_frames, pending_info = [], []
 
+            loop = asyncio.get_event_loop()
+
             async def flush():
+                # Batches of equally sized frames ride the three-deep device pipeline (upload stream -> detector -> post-process /
+                # recogniser streams, see _pipeline_push): results come back one or two batches later, in frame order.  Anything
+                # else drains the pipeline first and takes the reference-shaped route.
                 nonlocal frame_count
-                all_results.extend(await self._process_frame_batch(pending_frames, pending_info, output_dir))
+                if self._fast_path_ok(pending_frames):
+                    done = await loop.run_in_executor(self.executor, self._pipeline_push, list(pending_frames), list(pending_info))
+                else:
+                    done = await loop.run_in_executor(self.executor, self._pipeline_drain)
+                    done += await self._process_frame_batch(pending_frames, pending_info, output_dir)
+                all_results.extend(done)
                 frame_count += len(pending_frames)
                 pending_frames.clear()
                 pending_info.clear()
@@ -81,12 +91,59 @@ class VideoTextPipeline:
                         await progress_callback(progress, frame_count, total_frames)
             if pending_frames:
                 await flush()
+            all_results.extend(await loop.run_in_executor(self.executor, self._pipeline_drain))
             processing_time = time.time() - start_time
             return {"status": "success", "results": all_results,
                     "summary": self._generate_summary(all_results, processing_time, frame_count), "video_info": video_info}
         except Exception as e:
             logger.error(f"Video processing failed: {e}")
+            self._abandon_pipeline()
             return {"status": "failed", "error": str(e), "results": []}
+
+    # ---- device pipeline of the video loop: batch i uploads and detects while batch i-1 is recognised and batch i-2 is collected
+    def _pipeline_push(self, frames, frame_info) -> List[Dict]:
+        from .engine import PINNED, DeviceFrames
+        if getattr(self, "_inflight", None) is None:
+            self._inflight = []
+        if getattr(self, "_upload", None) is None:
+            self._upload = torch.cuda.Stream()
+        out = []
+        cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
+        for start in range(0, len(frames), cap):
+            chunk, info = frames[start:start + cap], frame_info[start:start + cap]
+            host = PINNED.take((len(chunk),) + tuple(chunk[0].shape), torch.uint8)  # pinned staging: the copy is truly asynchronous
+            staged = host.numpy()
+            for i, f in enumerate(chunk):
+                staged[i] = f
+            job = self.submit_detection(DeviceFrames(host, stream=self._upload))
+            job["info"], job["host"] = info, host
+            self._inflight.append(job)
+            if len(self._inflight) >= 2 and "rec" not in self._inflight[-2]:
+                self.submit_recognition(self._inflight[-2])
+            if len(self._inflight) >= 3:
+                out += self._retire(self._inflight.pop(0))
+        return out
+
+    def _retire(self, job) -> List[Dict]:
+        from .engine import PINNED
+        if "rec" not in job:
+            self.submit_recognition(job)
+        res = self.collect(job, job["info"])
+        PINNED.release(job["host"])
+        return res
+
+    def _pipeline_drain(self) -> List[Dict]:
+        out = []
+        while getattr(self, "_inflight", None):
+            out += self._retire(self._inflight.pop(0))
+        return out
+
+    def _abandon_pipeline(self):
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        self._inflight = []
 
     # ---------------------------------------------------------------------------------- batches
     def _fast_path_ok(self, frames) -> bool:
