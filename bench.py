@@ -197,20 +197,32 @@ def main():
         conv_us = sum(r[1] for r in convs) * 1e3  # per step, survey pass
         # algorithmic (reference-graph) FLOPs of the whole detector per step, SURVEY 8d: 69.8 GFLOP / frame for R18
         algo_flops_step = 2.0 * eng.macs_per_frame * B
-        traffic = None
+        traffic = traffic_detail = None
         try:  # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/, FETCH_SIZE x2 corrected)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_launch.json")))
-            if "classed" in name:
-                hits = [v for k, v in pmc.items() if "true>" in k and v["launches"] >= 3]
-                if hits:
-                    v = max(hits, key=lambda h: h["launches"])
-                    traffic = {"hbm_read_MB": v["hbm_read_MB_corrected_x2"], "hbm_write_MB": v["hbm_write_MB"],
-                               "source": "profiles/r01_pmc_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                         "median over launches, FETCH_SIZE x2 per the gfx950 note)"}
+
+            def pick(substr):
+                hits = [v for k, v in pmc.items() if substr in k and v["launches"] >= 3]
+                return max(hits, key=lambda h: h["launches"]) if hits else None
+
+            parts = []
+            if "head_entry_halo" in name:  # two launches make up this graph slot: interior classes + border tiles
+                parts = [pick("head_entry_halo_kernel"), pick("true>")]
+            elif "classed" in name:
+                parts = [pick("true>")]
+            parts = [v for v in parts if v]
+            if parts:
+                rd = sum(v["hbm_read_MB_corrected_x2"] for v in parts)
+                wr = sum(v["hbm_write_MB"] for v in parts)
+                traffic = int((rd + wr) * 1e6)
+                traffic_detail = {"hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2),
+                                  "source": "profiles/r01_pmc_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                            "median over launches, FETCH_SIZE x2 per the gfx950 note)"}
         except Exception:
-            traffic = None
+            traffic = traffic_detail = None
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
                     "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2),
                     "executed_gflop_per_launch": round(2 * macs / calls / 1e9, 3),
                     "alone_on_gpu": {"avg_launch_us": round(iso_ms / iso_calls * 1e3, 2),

@@ -308,55 +308,6 @@ __global__ void maxpool_kernel(const PoolParams p) {
     }
 }
 
-// Final head stage: ConvTranspose2d(64 -> 1, k=2, s=2) + sigmoid (text_detector.py:68-69).
-// N = 4 outputs per input pixel -> bandwidth bound: 8 lanes share one pixel (16 B each, one 128-B line),
-// partial dot products are combined with wave shuffles, lane 0 of the group writes the 2x2 fp32 block.
-struct FinalParams {
-    const half_t* in;   // [n, 322, 322, 64] ring 1
-    const float* w;     // [4][64]  (ky*2+kx major)
-    float bias;
-    float* prob;        // [n, 640, 640]
-    int n, h, w_in, in_hp, in_wp, ring;
-};
-
-__global__ __launch_bounds__(256) void final_convt_sigmoid_kernel(const FinalParams p) {
-    const int sub = threadIdx.x & 7;
-    float wr[4][8];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wr[o][e] = p.w[o * 64 + sub * 8 + e];
-    const int64_t total = (int64_t)p.n * p.h * p.w_in;
-    for (int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; pix < total;
-         pix += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-        const int img = (int)(pix / (p.h * p.w_in));
-        const int rem = (int)(pix - (int64_t)img * p.h * p.w_in);
-        const int y = rem / p.w_in, x = rem - y * p.w_in;
-        const half8 v = *(const half8*)(p.in + (((int64_t)img * p.in_hp + y + p.ring) * p.in_wp + x + p.ring) * 64 + sub * 8);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[e];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o] += f * wr[o][e];
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            acc[o] += __shfl_xor(acc[o], 1);
-            acc[o] += __shfl_xor(acc[o], 2);
-            acc[o] += __shfl_xor(acc[o], 4);
-        }
-        if (sub == 0) {
-            float* o0 = p.prob + ((int64_t)img * 640 + 2 * y) * 640 + 2 * x;
-            float s[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) s[o] = 1.f / (1.f + __expf(-(acc[o] + p.bias)));
-            *(float2*)o0 = make_float2(s[0], s[1]);
-            *(float2*)(o0 + 640) = make_float2(s[2], s[3]);
-        }
-    }
-}
-
 }  // namespace
 
 int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
@@ -410,12 +361,5 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
     const int64_t total = (int64_t)n * out.h * out.w * (in.c >> 3);
     const int blocks = (int)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
     hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, stream, p);
-    return -(int)hipGetLastError();
-}
-
-int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream) {
-    if (in.c != 64 || in.h != 320 || in.w != 320) return -1030;
-    FinalParams p{in.ptr, w4x64, bias, prob, n, in.h, in.w, in.hp, in.wp, in.ring};
-    hipLaunchKernelGGL(final_convt_sigmoid_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
     return -(int)hipGetLastError();
 }

@@ -34,7 +34,6 @@ void vtd_head_tail_pack_w1(const half_t* w1_gemm, half_t* packed);
 void vtd_head_tail_pack_w2(const float* w2, half_t* packed);
 int vtd_launch_head_tail(const TensorDesc& in, const half_t* w1, const float* bias1, const half_t* w2, float b2, float* out, int n,
                          hipStream_t stream);
-int vtd_launch_final_convt_sigmoid(const TensorDesc& in, const float* w4x64, float bias, float* prob, int n, hipStream_t stream);
 
 int vtd_launch_crop_resize(const uint8_t* frames, int H, int W, const int32_t* boxes, int ncrops, uint8_t* out, hipStream_t s);
 int vtd_launch_crnn_conv1(const uint8_t* in_u8, const float* in_f32, const half_t* w, const float* bias, half_t* out, int n, hipStream_t s);
