@@ -206,8 +206,8 @@ def main():
                 return max(hits, key=lambda h: h["launches"]) if hits else None
 
             parts = []
-            if "head_entry_halo" in name:  # two launches make up this graph slot: interior classes + border tiles
-                parts = [pick("head_entry_halo_kernel"), pick("true>")]
+            if "head_entry_halo" in name:
+                parts = [pick("head_entry_halo_kernel")]
             elif "classed" in name:
                 parts = [pick("true>")]
             parts = [v for v in parts if v]
@@ -232,7 +232,8 @@ def main():
                                              "recogniser and post-process streams share the CUs with it, which stretches its wall time"},
                     "note": "achieved = FLOPs this launch EXECUTES / its HIP-event time on the launch stream; the composed conv replaces "
                             "lateral(C2)+top-down add+P2 smooth+head conv of the reference graph with ~3x fewer FLOPs, so the "
-                            "reference-graph rate over all matrix launches is given as net_algorithmic_tflops",
+                            "reference-graph rate over all matrix launches is given as net_algorithmic_tflops; peak = nominal dense fp16 "
+                            "(a bare MFMA loop sustains ~2.3 PFLOP/s on this part, tools/mfma_peak.hip)",
                     "all_mfma_launches_tflops_executed": round(sum(2 * r[2] for r in convs) / (conv_us * 1e-6) / 1e12, 2),
                     "net_algorithmic_tflops": round(algo_flops_step / (conv_us * 1e-6) / 1e12, 2),
                     "detector_mfma_launches_us_per_step": round(conv_us, 1)}
