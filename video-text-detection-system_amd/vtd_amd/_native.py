@@ -62,6 +62,9 @@ def load():
     """dlopen the library and bind every declared symbol (no device needed)."""
     global _lib
     if _lib is None:
+        # torch first: it ships its own libamdhip64; loaded after ours the process ends up with two HIP runtimes and the
+        # second one to initialise sees no device (observed with build() + smoke() in one process)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise NativeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950)")
         lib = C.CDLL(LIB_PATH)
