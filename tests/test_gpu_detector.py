@@ -222,6 +222,24 @@ def test_dbnet_r50(hip):
         eng.close()
 
 
+def test_dbnet_r50_halo_plane_head_entry(hip, monkeypatch):
+    """ResNet-50: C2 has 256 channels, so the composed head entry walks 4 channel chunks x 4 parity planes of C2 (136 K-steps)
+    on the halo-plane kernel; probabilities against the fp32 oracle."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    monkeypatch.setenv("VTD_FORCE_CLASSED_CFG", "102")
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet50"), seed=6)
+    eng = DetectorEngine("resnet50", sd, max_batch=1)
+    try:
+        x = torch.randn(1, 3, 640, 640, generator=torch.Generator().manual_seed(41))
+        prob = eng.forward(x)["probability"].cpu()
+        names = [r[0] for r in detector_profile(eng)]
+        ref = onets.dbnet_forward(x, sd, "resnet50")
+        assert any("head_entry_halo" in n for n in names), names
+        assert float((prob - ref["probability"]).abs().max()) <= 2e-3
+    finally:
+        eng.close()
+
+
 def test_macs_accounting(r18):
     eng, _ = r18
     assert eng.macs_per_frame == pytest.approx(34.91e9, rel=0.01)  # SURVEY 8d: 69.8 GFLOP / frame
