@@ -111,3 +111,22 @@ def test_text_recognizer_surface_and_mock_seam(hip):
     assert rec.recognize_batch([np.zeros((0, 5, 3), np.uint8)]) == [{"text": "", "confidence": 0.0}]
     with pytest.raises(NotImplementedError):
         TextRecognizer(use_transformer=True)
+
+
+def test_crnn_halo_convs_forced(hip, golden_dir, monkeypatch):
+    """The CRNN's stride-1 3x3 layers on the halo-tile kernel (8x32 pixel blocks on the 8x32 maps, 16x16 on 16x64) wherever it
+    applies, not only where the autotune happens to pick it: same golden logits, same tolerance."""
+    from vtd_amd.engine import RecognizerEngine
+    monkeypatch.setenv("VTD_FORCE_HALO", "1")
+    sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    eng = RecognizerEngine(97, sd, max_crops=8)
+    try:
+        g = np.load(os.path.join(golden_dir, "crnn_g1.npz"))
+        x = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(21))
+        logits = eng.forward_logits(x).cpu().numpy()
+    finally:
+        eng.close()
+    ref = g["logits"]
+    err = float(np.abs(logits - ref).max())
+    print("halo-forced logit max abs err", err)
+    assert err <= 3e-3 * float(ref.max() - ref.min()) + 1e-3
