@@ -129,7 +129,7 @@ def test_dbnet_fused_stem_pool(r18, r18_fused):
         eng_f.read_tap("stem", 1)  # never materialised
 
 
-@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 102])
+@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 102, 103])
 def test_composed_head_entry_every_tile_configuration(hip, monkeypatch, cfg):
     """The composed conv on each of its tile configurations (128- and 256-row pixel-list tiles, 2 / 3 LDS stages): same
     probabilities as the fp32 oracle, borders included (the per-class padding rows of the two list cuts differ)."""
@@ -148,7 +148,8 @@ def test_composed_head_entry_every_tile_configuration(hip, monkeypatch, cfg):
     finally:
         eng.close()
     want = {8: "128,64,s2,classed", 9: "128,64,s3,classed", 10: "256,64,s2,classed", 11: "256,64,s3,classed",
-            102: "head_entry_halo"}[cfg]  # 102: interior classes on the halo-plane kernel, border classes on 128-row tiles
+            102: "head_entry_halo M", 103: "head_entry_halo256"}[cfg]  # 102 / 103: interior classes on the halo-plane kernels
+    # (8x16 / 16x16 pixel blocks), border classes on 128-row gathered tiles
     assert any(want in n for n in names), names
     assert _rel(h1, h1_ref) < 1.5e-2
     assert float(np.abs(prob - ref["probability"].numpy()).max()) <= 2e-3
@@ -222,11 +223,12 @@ def test_dbnet_r50(hip):
         eng.close()
 
 
-def test_dbnet_r50_halo_plane_head_entry(hip, monkeypatch):
+@pytest.mark.parametrize("cfg", ["102", "103"])
+def test_dbnet_r50_halo_plane_head_entry(hip, monkeypatch, cfg):
     """ResNet-50: C2 has 256 channels, so the composed head entry walks 4 channel chunks x 4 parity planes of C2 (136 K-steps)
     on the halo-plane kernel; probabilities against the fp32 oracle."""
     from vtd_amd.engine import DetectorEngine, detector_profile
-    monkeypatch.setenv("VTD_FORCE_CLASSED_CFG", "102")
+    monkeypatch.setenv("VTD_FORCE_CLASSED_CFG", cfg)
     sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet50"), seed=6)
     eng = DetectorEngine("resnet50", sd, max_batch=1)
     try:

@@ -224,6 +224,213 @@ __global__ __launch_bounds__(NW * 64) void head_entry_halo_kernel(const HeadHalo
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Same computation, bigger register tiles.  tools/mfma_peak.hip: the part is power bound, a wave issues an MFMA at best
+// every 17 cycles and what a kernel can change is the LDS traffic per MFMA.  Above, a wave owns 64 pixels x 32 channels
+// (6 fragment reads per 8 MFMAs) and four waves per SIMD hide each other's LDS latency.  Here a tile is a 16 x 16 block of
+// same-parity pixels (256 GEMM rows, halo 18 x 18), four waves of 64 pixels x 64 channels each (8 reads per 16 MFMAs: a third
+// less LDS traffic, a third less halo per pixel), two workgroups per CU, and the latency hiding is done by hand as in
+// conv3x3_c64_persistent_kernel: the 8 fragment reads of half K-step h+1 are issued under the 16 MFMAs of half-step h.
+// That needs the NEXT K-step's weights in LDS one step early, hence a 4-stage weight ring with a counted wait that leaves
+// only the newest stage in flight.  Across a group switch (new halo) there is nothing to prefetch: the first half-step of a
+// group reads its fragments in the open.
+constexpr int HB_HW = 18, HB_ROWS = 324, HB_PIECES = 41, HB_HALO_BYTES = 41 * 1024, HB_RING = 4;
+
+__global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHaloParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const hb = smem;
+    char* const bring = smem + HB_HALO_BYTES;
+    int* const stab = (int*)(bring + HB_RING * HE_BSTAGE);
+
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int cls4 = tile & 3;
+    tile >>= 2;
+    const int bx = tile % p.blocks_x;
+    tile /= p.blocks_x;
+    const int by = tile % p.blocks_y;
+    const int img = tile / p.blocks_y;
+    const int py = cls4 >> 1, px = cls4 & 1;
+    const int ly_min = py ? 0 : 1, lx_min = px ? 0 : 1;
+    const int ly_cnt = p.h / 2 - 1, lx_cnt = p.w / 2 - 1;
+    const int ly0 = ly_min + by * 16, lx0 = lx_min + bx * 16;
+    const half_t* wcls = p.wgt + (int64_t)((py ? 2 : 1) * 4 + (px ? 2 : 1)) * 64 * p.K;
+    const int* steps = p.steps + (int64_t)cls4 * p.nsteps * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 3, fr = lane & 15, fq = lane >> 4;
+
+    auto issue_halo = [&](int src, int chunk) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int piece = w + 4 * k;
+            if (piece >= HB_PIECES) break;
+            int row = piece * 8 + lrow;
+            row = row < HB_ROWS ? row : HB_ROWS - 1;
+            const int i = row / HB_HW, j = row - i * HB_HW;
+            const int c_log = (lane & 7) ^ (row & 6);
+            const half_t* g;
+            if (src < 4) {
+                int yy = 2 * (ly0 - 1 + i) + (src >> 1) + p.c2_ring, xx = 2 * (lx0 - 1 + j) + (src & 1) + p.c2_ring;
+                yy = yy < p.c2_hp ? yy : p.c2_hp - 1;
+                xx = xx < p.c2_wp ? xx : p.c2_wp - 1;
+                g = p.c2 + ((int64_t)(img * p.c2_hp + yy) * p.c2_wp + xx) * p.c2_c + chunk * 64 + c_log * 8;
+            } else {
+                int yy = ly0 - 1 + i + p.l3_ring, xx = lx0 - 1 + j + p.l3_ring;
+                yy = yy < p.l3_hp ? yy : p.l3_hp - 1;
+                xx = xx < p.l3_wp ? xx : p.l3_wp - 1;
+                g = p.l3 + ((int64_t)(img * p.l3_hp + yy) * p.l3_wp + xx) * 256 + chunk * 64 + c_log * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)g, (VTD_AS3 void*)(hb + piece * 1024), 16, 0, 0);
+        }
+    };
+    const half_t* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + w) * 8 + lrow;
+        bsrc[i] = wcls + (int64_t)row * p.K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto issue_b = [&](int koff, int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bsrc[i] + koff),
+                                             (VTD_AS3 void*)(bring + stage * HE_BSTAGE + (i * 4 + w) * 1024), 16, 0, 0);
+    };
+
+    int hbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = w * 64 + j * 16 + fr;
+        hbase[j] = (m >> 4) * HB_HW + (m & 15);
+    }
+    const int b_lane_off = fr * 128;
+    const int bswz = (fr >> 1) & 7;
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < 2 * p.nsteps; i += 256) stab[i] = steps[i];
+    __syncthreads();
+    auto koff_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * s]); };
+    auto desc_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * (s < p.nsteps ? s : p.nsteps - 1) + 1]); };
+    // fragments of (tap offset, ring stage, half kk)
+    auto load_frags = [&](int tapoff, int stage, int kk, half8 (&af)[4], half8 (&bf)[4]) {
+        const char* sb = bring + stage * HE_BSTAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hrow = hbase[j] + tapoff;
+            af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ (hrow & 6)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + (((fq + 4 * kk) ^ bswz) << 4));
+    };
+
+    // Step descriptors come out of LDS too.  They are read at the END of a step, behind that step's fragment prefetch, and
+    // consumed after the wait at the top of the next step (which is due anyway for the prefetched fragments): read anywhere
+    // else they put an s_waitcnt lgkmcnt(0) in front of the MFMAs and the fragment prefetch is lost.
+    auto raw_k = [&](int s) { return stab[2 * (s < p.nsteps ? s : p.nsteps - 1)]; };
+    auto raw_t = [&](int s) { return stab[2 * (s < p.nsteps ? s : p.nsteps - 1) + 1]; };
+    int d_t = __builtin_amdgcn_readfirstlane(raw_t(0)), n_t = __builtin_amdgcn_readfirstlane(raw_t(1));
+    issue_halo((d_t >> 9) & 7, d_t >> 12);
+#pragma unroll
+    for (int a = 0; a < HB_RING - 1; ++a)
+        if (a < p.nsteps) issue_b(koff_of(a), a);
+    int v_k3 = raw_k(HB_RING - 1), v_t2 = raw_t(2);  // koff(s+3), desc(s+2) for s = 0 (vector copies, made uniform after the wait)
+    half8 fa[2][4], fb[2][4];
+    bool have_frags = false;  // fragments of (s, half 0) already prefetched during step s-1
+    bool fresh_halo = true;
+    int stage = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, a_wait = 0, a_comp = 0, a_sw = 0, t_begin = 0;
+    if (p.stamps) t_begin = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < p.nsteps; ++s) {
+        if (p.stamps) t0 = __builtin_amdgcn_s_memtime();
+        // all waves: weights of steps s and s+1 landed (only the newest ring stage may still be in flight); a fresh halo is newer
+        // than every weight load, so it needs the full wait
+        if (fresh_halo || s + 2 >= p.nsteps) he_wait_vmcnt<0>(); else he_wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+        const int k3 = __builtin_amdgcn_readfirstlane(v_k3), nn_t = __builtin_amdgcn_readfirstlane(v_t2);
+        if (s + HB_RING - 1 < p.nsteps) issue_b(k3, (stage + HB_RING - 1) & 3);
+        const int tapoff = d_t & 0xff;
+        const bool next_same_group = s + 1 < p.nsteps && !((n_t >> 8) & 1);
+        if (!have_frags) load_frags(tapoff, stage, 0, fa[0], fb[0]);
+        // half 0: prefetch half 1 of this step
+        load_frags(tapoff, stage, 1, fa[1], fb[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // half 1: prefetch half 0 of the next step (same halo group only), then the descriptors of the steps after it
+        if (next_same_group) load_frags(n_t & 0xff, (stage + 1) & 3, 0, fa[0], fb[0]);
+        v_k3 = raw_k(s + HB_RING);
+        v_t2 = raw_t(s + 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1][i], fa[1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        have_frags = next_same_group;
+        fresh_halo = false;
+        if (p.stamps) {
+            asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+            t2 = __builtin_amdgcn_s_memtime();
+            a_wait += t1 - t0;
+            a_comp += t2 - t1;
+        }
+        if (s + 1 < p.nsteps && !next_same_group) {
+            __builtin_amdgcn_s_barrier();  // group switch: every wave is done with the halo before it is replaced
+            issue_halo((n_t >> 9) & 7, n_t >> 12);
+            fresh_halo = true;
+            if (p.stamps) a_sw += __builtin_amdgcn_s_memtime() - t2;
+        }
+        d_t = n_t;
+        n_t = nn_t;
+        stage = (stage + 1) & 3;
+    }
+
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + (int64_t)blockIdx.x * 4;
+        o[0] = a_wait; o[1] = a_comp; o[2] = a_sw; o[3] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+    // ---- epilogue: accumulators -> fp32 LDS tile -> position-dependent bias, ReLU, 16-byte NHWC stores
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(floatx4*)(smem + (w * 64 + j * 16 + fr) * HE_EPI_ROW + (i * 16 + fq * 4) * 4) = acc[i][j];
+    __syncthreads();
+    const int cc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int m = it * 32 + r0;
+        const int r = m >> 4, c = m & 15;
+        if (ly0 + r >= ly_min + ly_cnt || lx0 + c >= lx_min + lx_cnt) continue;
+        const int oy = 2 * (ly0 + r) + py, ox = 2 * (lx0 + c) + px;
+        const int yc = oy == 1 ? 1 : oy == p.h - 2 ? 3 : 2;
+        const int xc = ox == 1 ? 1 : ox == p.w - 2 ? 3 : 2;
+        const float* bt = p.bias_tab + (yc * 5 + xc) * 64 + cc * 8;
+        const floatx4 b0 = *(const floatx4*)bt, b1 = *(const floatx4*)(bt + 4);
+        const floatx4 v0 = *(const floatx4*)(smem + m * HE_EPI_ROW + cc * 32) + b0;
+        const floatx4 v1 = *(const floatx4*)(smem + m * HE_EPI_ROW + cc * 32 + 16) + b1;
+        half8 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hv[e] = (half_t)fmaxf(v0[e], 0.f);
+            hv[4 + e] = (half_t)fmaxf(v1[e], 0.f);
+        }
+        *(half8*)(p.out + (((int64_t)img * p.out_hp + oy + p.out_ring) * p.out_wp + ox + p.out_ring) * 64 + cc * 8) = hv;
+    }
+}
+
 }  // namespace
 
 // Step table of one interior class (py, px): entries {k offset into the [64][K] class matrix, tapoff | first<<8 | src<<9 | chunk<<12}.
@@ -255,7 +462,7 @@ int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36
     return s;
 }
 
-int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, hipStream_t stream) {
+int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream) {
     if (!c.plist || !c.in2 || !c.bias_tab || c.cout != 64 || c.in2_c != 256 || (c.in_c & 63) || c.in_y0 < 0 || (c.img_h & 1) || (c.img_w & 1) ||
         c.tiles_per_img <= 0 || nsteps != 25 * (c.in_c / 64) + 36 || c.K != 25 * c.in_c + 9 * 256)
         return -2301;
@@ -268,6 +475,38 @@ int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int ns
     const int cnt_y = c.img_h / 2 - 1, cnt_x = c.img_w / 2 - 1;
     p.blocks_y = (cnt_y + 7) / 8; p.blocks_x = (cnt_x + 15) / 16;
     if (p.n <= 0 || p.c2_ring < 2 || p.l3_ring < 1) return -2302;
+    if (big_tiles) {  // 16 x 16 pixel blocks, 64 x 64 register tiles, hand-pipelined fragment reads
+        p.blocks_y = (cnt_y + 15) / 16; p.blocks_x = (cnt_x + 15) / 16;
+        p.stamps = nullptr;
+        const int lds256 = HB_HALO_BYTES + HB_RING * HE_BSTAGE + 2 * nsteps * 4;
+        if (lds256 < 256 * HE_EPI_ROW) return -2303;
+        static bool attr256 = false;
+        if (!attr256) {
+            hipError_t e = hipFuncSetAttribute((const void*)head_entry_halo256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return -(int)e;
+            attr256 = true;
+        }
+        const int grid256 = p.n * p.blocks_y * p.blocks_x * 4;
+        static const bool stamps256 = [] { const char* e = getenv("VTD_HALO_STAMPS"); return e && e[0] == '1'; }();
+        if (stamps256) {  // debug: where a workgroup's K loop goes (synchronises!)
+            unsigned long long* dev = nullptr;
+            if (hipMalloc(&dev, (size_t)grid256 * 32) != hipSuccess) return -2304;
+            p.stamps = dev;
+            hipLaunchKernelGGL(head_entry_halo256_kernel, dim3(grid256), dim3(256), lds256, stream, p);
+            (void)hipStreamSynchronize(stream);
+            unsigned long long* h = (unsigned long long*)malloc((size_t)grid256 * 32);
+            (void)hipMemcpy(h, dev, (size_t)grid256 * 32, hipMemcpyDeviceToHost);
+            double a = 0, b = 0, cc = 0, d = 0;
+            for (int i = 0; i < grid256; ++i) { a += (double)h[4 * i]; b += (double)h[4 * i + 1]; cc += (double)h[4 * i + 2]; d += (double)h[4 * i + 3]; }
+            fprintf(stderr, "[head_entry_halo256 stamps] grid %d: per workgroup cycles: wait+barrier %.0f  compute %.0f  group switch %.0f  K loop total %.0f\n",
+                    grid256, a / grid256, b / grid256, cc / grid256, d / grid256);
+            free(h);
+            (void)hipFree(dev);
+            return 0;
+        }
+        hipLaunchKernelGGL(head_entry_halo256_kernel, dim3(grid256), dim3(256), lds256, stream, p);
+        return -(int)hipGetLastError();
+    }
     static const int ring = [] { const char* e = getenv("VTD_HEAD_HALO_RING"); const int r = e ? atoi(e) : 2; return (r == 2 || r == 3) ? r : 2; }();
     static const int nw = [] { const char* e = getenv("VTD_HEAD_HALO_WAVES"); return (e && atoi(e) == 2) ? 2 : 4; }();
     const int lds = HE_HALO_BYTES + ring * HE_BSTAGE + 2 * nsteps * 4;  // halo + weight ring + step table (>= the 34 KB epilogue tile)

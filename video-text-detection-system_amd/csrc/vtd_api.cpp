@@ -26,7 +26,7 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
-int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, hipStream_t stream);
+int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream);
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
 bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
@@ -155,6 +155,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
 // Tile "configuration" kHaloCfg selects the halo-tile kernel (conv_halo.hip) instead of an implicit-GEMM tile shape.
 static const int kHaloCfg = 100;
 static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 64 -> 64 channels
+static const int kHeadEntryHalo256Cfg = 103;  // same, 16x16 pixel blocks with 64x64 register tiles (hand-pipelined)
 static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
@@ -165,9 +166,9 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
-    if (cfg == kHeadEntryHaloCfg) {  // interior classes only; the border tiles are the next graph slot (launch_border_tiles)
+    if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) {  // interior classes only; border tiles = the next graph slot
         if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
-        return vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, s);
+        return vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, cfg == kHeadEntryHalo256Cfg ? 1 : 0, s);
     }
     if (cfg == kHaloCfg || cfg == kHaloC64Cfg) {
         int bn = 0, tw = 0;
@@ -199,7 +200,7 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     int best_id = -1, rc = 0;
     if (p.plist) {  // tests: pin the composed conv to one tile configuration (8..11)
         const char* fc = std::getenv("VTD_FORCE_CLASSED_CFG");
-        if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || (std::atoi(fc) == kHeadEntryHaloCfg && c.he_steps))) {
+        if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || ((std::atoi(fc) == kHeadEntryHaloCfg || std::atoi(fc) == kHeadEntryHalo256Cfg) && c.he_steps))) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             *best_cfg = std::atoi(fc);
@@ -217,18 +218,20 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; best_id = cfg; }
     }
-    if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernel + border tiles
-        auto both = [&]() { int r = launch_conv_op(c, n, s, kHeadEntryHaloCfg); return r ? r : launch_border_tiles(c, n, s); };
-        if (!(rc = both())) {
+    if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernels + border tiles
+        for (int variant = 0; variant < 2 && !rc; ++variant) {
+            const int vcfg = variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
+            auto both = [&]() { int r = launch_conv_op(c, n, s, vcfg); return r ? r : launch_border_tiles(c, n, s); };
+            if ((rc = both())) break;
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = both();
             (void)hipEventRecord(e1, s);
             if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            // within noise of the gathered tiles it wins the tie: a third of the HBM reads (PMC) and of the LDS-DMA traffic,
-            // which is what the other two streams of the pipeline compete for
-            if (!rc && ms < best * 1.03f) { best = ms; best_id = kHeadEntryHaloCfg; }
+            // within noise of the gathered tiles the halo planes win the tie: a third of the HBM reads (PMC) and of the LDS-DMA
+            // traffic, which is what the other two streams of the pipeline compete for
+            if (!rc && ms < best * (best_id == kHeadEntryHaloCfg ? 1.0f : 1.03f)) { best = ms; best_id = vcfg; }
         }
     }
     int hbn = 0, htw = 0;
@@ -1151,7 +1154,7 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
         const Op& o = d->ops[oi];
         int rc = 0;
         if (o.final_slot == 1 && !thresh_dev) continue;
-        if (o.kind == Op::BORDER && (oi == 0 || cfgs[oi - 1] != kHeadEntryHaloCfg)) continue;  // the gathered kernel did every class
+        if (o.kind == Op::BORDER && (oi == 0 || (cfgs[oi - 1] != kHeadEntryHaloCfg && cfgs[oi - 1] != kHeadEntryHalo256Cfg))) continue;  // the gathered kernel did every class
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool prof = d->profiling && (d->prof_only < 0 || d->prof_only == (int)oi);
         if (prof) {
@@ -1219,7 +1222,10 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                                       "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        if (cfg == kHeadEntryHaloCfg)
+        if (cfg == kHeadEntryHalo256Cfg)
+            std::snprintf(name, name_cap, "head_entry_halo256 M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
+                          "next slot)", c.ho * c.wo, c.cout, c.K);
+        else if (cfg == kHeadEntryHaloCfg)
             std::snprintf(name, name_cap, "head_entry_halo M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
                           "next slot)", c.ho * c.wo, c.cout, c.K);
         else if (cfg == kHaloCfg || cfg == kHaloC64Cfg)
