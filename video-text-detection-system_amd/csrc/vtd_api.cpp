@@ -233,6 +233,9 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
                 (void)hipEventElapsedTime(&t, e0, e1);
                 ms = t * 0.75f < ms ? t * 0.75f : ms;  // scaled to the 3 launches the other candidates are timed on
             }
+            if (const char* v = std::getenv("VTD_AUTOTUNE_VERBOSE"); v && v[0] == '1')
+                std::fprintf(stderr, "[autotune] head entry variant %d: %.1f us per launch incl. border tiles (best so far %.1f, cfg %d)\n", vcfg,
+                             ms / 3.f * 1e3f, best / 3.f * 1e3f, best_id);
             // within noise of the gathered tiles the halo planes win the tie: a third of the HBM reads (PMC) and of the LDS-DMA
             // traffic, which is what the other two streams of the pipeline compete for
             if (!rc && ms < best * (best_id == kHeadEntryHaloCfg ? 1.0f : 1.03f)) { best = ms; best_id = vcfg; }
@@ -258,6 +261,9 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *best_cfg = best_id;
+    if (const char* v = std::getenv("VTD_AUTOTUNE_VERBOSE"); v && v[0] == '1')
+        std::fprintf(stderr, "[autotune] M=%d N=%d K=%d%s -> cfg %d (%.1f us per launch)\n", p.M, p.cout, p.K, p.plist ? " classed" : "", best_id,
+                     best / 3.f * 1e3f);
     return rc;
 }
 
