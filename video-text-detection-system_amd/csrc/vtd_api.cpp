@@ -219,6 +219,7 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
         if (ms < best) { best = ms; best_id = cfg; }
     }
     if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernels + border tiles
+        const float best_gathered = best;
         for (int variant = 0; variant < 2 && !rc; ++variant) {
             const int vcfg = variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
             auto both = [&]() { int r = launch_conv_op(c, n, s, vcfg); return r ? r : launch_border_tiles(c, n, s); };
@@ -236,9 +237,12 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
             if (const char* v = std::getenv("VTD_AUTOTUNE_VERBOSE"); v && v[0] == '1')
                 std::fprintf(stderr, "[autotune] head entry variant %d: %.1f us per launch incl. border tiles (best so far %.1f, cfg %d)\n", vcfg,
                              ms / 3.f * 1e3f, best / 3.f * 1e3f, best_id);
-            // within noise of the gathered tiles the halo planes win the tie: a third of the HBM reads (PMC) and of the LDS-DMA
-            // traffic, which is what the other two streams of the pipeline compete for
-            if (!rc && ms < best * (best_id == kHeadEntryHaloCfg ? 1.0f : 1.03f)) { best = ms; best_id = vcfg; }
+            // The three implementations are within a few percent of one another in situ while this back-to-back timing
+            // flatters the gathered kernel (its inputs stay hot in the Infinity Cache between repetitions): the halo-plane
+            // kernels win anything up to 10 % (a third of the HBM reads and LDS-DMA traffic, which the other two streams of
+            // the pipeline compete for), the 16x16-block variant ahead of the 8x16 one.
+            const float ref = best_id == kHeadEntryHaloCfg ? best_gathered : best;
+            if (!rc && ms < ref * (variant ? 1.10f : 1.05f)) { best = ms; best_id = vcfg; }
         }
     }
     int hbn = 0, htw = 0;
