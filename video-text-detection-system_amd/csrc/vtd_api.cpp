@@ -185,7 +185,9 @@ static int launch_border_tiles(const ConvOp& c, int n, hipStream_t s) {
     fill_conv_params(c, n, pb);
     pb.tile_combo = c.tile_combo_border; pb.tiles_per_img = c.tiles_border; pb.M = n * c.tiles_border * 128;
     pb.plist_b = nullptr; pb.tile_combo_b = nullptr; pb.tiles_per_img_b = 0;
-    return vtd_launch_conv(pb, 8, s);
+    // 384 tiles on 256 CUs: one latency-bound round, so the 3-stage ring (two K-steps of loads in flight) beats the 2-stage one
+    // that wins when several workgroups share a CU (41 vs 53 us)
+    return vtd_launch_conv(pb, 9, s);
 }
 
 // Times every valid tile configuration of one convolution at batch n and returns the fastest (HIP events on `s`).
@@ -1251,7 +1253,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
     } else if (o.kind == Op::BORDER) {
-        std::snprintf(name, name_cap, "conv_igemm<128,64,s2,classed> border classes of the composed head entry (%d tiles/img)", o.conv.tiles_border);
+        std::snprintf(name, name_cap, "conv_igemm<128,64,s3,classed> border classes of the composed head entry (%d tiles/img)", o.conv.tiles_border);
     } else if (o.kind == Op::HEADTAIL) {
         std::snprintf(name, name_cap, "head_tail ConvT1+BN+ReLU+ConvT2+sigmoid fused M/img=%d N=256 K=64", o.conv.ho * o.conv.wo);
     } else if (o.kind == Op::STEMPOOL) {
