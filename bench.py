@@ -148,6 +148,10 @@ def main():
         torch.cuda.synchronize()
 
     drain = drain_full if args.workload == "full" else drain_detector
+    # one priming step whatever --warmup says: the first call at a batch size runs the per-layer autotune and the workspace
+    # allocations (hundreds of ms), which are set-up cost, not a step of the path
+    step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()
