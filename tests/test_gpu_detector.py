@@ -164,7 +164,7 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
     x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(21))
     ref = onets.dbnet_forward(x, sd, "resnet18", return_taps=True)
     outs = {}
-    for mode in ("1", "2", "0"):
+    for mode in ("1", "2", "3", "0"):
         monkeypatch.setenv("VTD_FORCE_HALO", mode)
         monkeypatch.setenv("VTD_HALO_CONV", "0" if mode == "0" else "1")
         eng = DetectorEngine("resnet18", sd, max_batch=2, options={"fuse_fpn_head": 0})
@@ -176,7 +176,7 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
         finally:
             eng.close()
         outs[mode] = (prob, taps, names)
-    for mode in ("1", "2"):  # 2 = layer1 additionally on the persistent resident-weight variant
+    for mode in ("1", "2", "3"):  # 2 = layer1 additionally on the persistent resident-weight variant, 3 = hand-pipelined conv_halo64
         prob, taps, names = outs[mode]
         errs = {n: _rel(taps[i], ref["taps"][i].numpy()) for i, n in enumerate(("c2", "c3", "c4", "c5"))}
         errs["p2"] = _rel(taps[4], ref["p2"].numpy())
@@ -189,6 +189,8 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
         assert sum("conv_halo" in n for n in names) >= 7  # layer1 (4) + layer2 (3) at least
         if mode == "2":
             assert sum("c64_persistent" in n for n in names) == 4
+        if mode == "3":
+            assert sum("conv_halo64" in n for n in names) >= 7
     assert not any("conv_halo" in n for n in outs["0"][2])
 
 

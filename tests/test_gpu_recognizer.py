@@ -113,11 +113,12 @@ def test_text_recognizer_surface_and_mock_seam(hip):
         TextRecognizer(use_transformer=True)
 
 
-def test_crnn_halo_convs_forced(hip, golden_dir, monkeypatch):
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_crnn_halo_convs_forced(hip, golden_dir, monkeypatch, mode):
     """The CRNN's stride-1 3x3 layers on the halo-tile kernel (8x32 pixel blocks on the 8x32 maps, 16x16 on 16x64) wherever it
     applies, not only where the autotune happens to pick it: same golden logits, same tolerance."""
     from vtd_amd.engine import RecognizerEngine
-    monkeypatch.setenv("VTD_FORCE_HALO", "1")
+    monkeypatch.setenv("VTD_FORCE_HALO", mode)  # 1: first-generation halo kernel, 3: hand-pipelined conv_halo64
     sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
     eng = RecognizerEngine(97, sd, max_crops=8)
     try:

@@ -216,6 +216,194 @@ __global__ __launch_bounds__((BN / 64) * 256) void conv_halo_kernel(const HaloPa
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Second generation of the halo-tile kernel for any Cin (multiple of 64) and 64 output channels per workgroup, built like
+// head_entry_halo256_kernel (head_entry_halo.hip): 256-pixel block, four waves of 64 pixels x 64 channels, ONE halo buffer
+// (the fetch of the next channel chunk's halo is exposed; the second workgroup on the CU covers it), a 4-stage weight ring
+// whose counted wait leaves only the newest stage in flight, so that the fragment reads of half K-step h+1 -- including the
+// first half of the NEXT K-step -- are issued under the MFMAs of half-step h.  41 KB halo + 32 KB ring = 74 KB: two
+// workgroups per CU.  Layers with more output channels run one workgroup per 64 of them on the same pixel block (the halo is
+// then fetched once per 64 output channels, out of L2).
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv_halo64_kernel(const HaloParams p) {
+    constexpr int TH = 256 / TW, HWD = TW + 2, HROWS = (TH + 2) * HWD, HPIECES = (HROWS + 7) / 8, HBYTES = HPIECES * 1024;
+    constexpr int HPW = (HPIECES + 3) / 4, BSTAGE = 64 * 128, EPI_ROW = 64 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const hb = smem;
+    char* const bring = smem + HBYTES;
+
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int tn = tile % p.tiles_n;
+    tile /= p.tiles_n;
+    const int tx = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    const int img = tile / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = tn * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 3, fr = lane & 15, fq = lane >> 4;
+    const int K = 9 * p.cin, nchunks = p.cin >> 6, nsteps = nchunks * 9;
+
+    // (source offsets are recomputed per chunk: once every nine K-steps, cheaper than 11 live registers under a 256-VGPR cap)
+    auto issue_halo = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            if (w + 4 * k >= HPIECES) break;
+            int row = (w + 4 * k) * 8 + lrow;
+            row = row < HROWS ? row : HROWS - 1;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            int gy = y0 - 1 + hy + p.in_ring, gx = x0 - 1 + hx + p.in_ring;
+            gy = gy < p.in_hp ? gy : p.in_hp - 1;
+            gx = gx < p.in_wp ? gx : p.in_wp - 1;
+            const int off = ((img * p.in_hp + gy) * p.in_wp + gx) * p.cin + ((lane & 7) ^ (row & 6)) * 8;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.in + off + chunk * 64), (VTD_AS3 void*)(hb + (w + 4 * k) * 1024), 16, 0, 0);
+        }
+    };
+    const half_t* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + w) * 8 + lrow;
+        bsrc[i] = p.wgt + (int64_t)(n0 + row) * K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto issue_b = [&](int step, int stage) {
+        const int chunk = step / 9, tap = step - chunk * 9;
+        const int koff = tap * p.cin + chunk * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bsrc[i] + koff), (VTD_AS3 void*)(bring + stage * BSTAGE + (i * 4 + w) * 1024), 16, 0, 0);
+    };
+
+    int hbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = w * 64 + j * 16 + fr;
+        hbase[j] = (m / TW) * HWD + (m % TW);
+    }
+    const int b_lane_off = fr * 128;
+    const int bswz = (fr >> 1) & 7;
+    auto load_frags = [&](int tapoff, int stage, int kk, half8 (&af)[4], half8 (&bf)[4]) {
+        const char* sb = bring + stage * BSTAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hrow = hbase[j] + tapoff;
+            af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ (hrow & 6)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + (((fq + 4 * kk) ^ bswz) << 4));
+    };
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    issue_halo(0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    issue_b(2, 2);
+    half8 fa[2][4], fb[2][4];
+    int s = 0, stage = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll 1  // (unrolled, the 72 fragment addresses of a chunk are all kept live and spill)
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            // tap 0 follows a fresh halo (newer than every weight load): full wait; otherwise only the newest ring stage may be
+            // in flight, i.e. the weights of steps s and s+1 have landed for every wave once the barrier is passed
+            if (tap == 0 || s + 2 >= nsteps) hl_wait_vmcnt<0>(); else hl_wait_vmcnt<2>();
+            __builtin_amdgcn_s_barrier();
+            if (s + 3 < nsteps) issue_b(s + 3, (stage + 3) & 3);
+            const int tapoff = (tap / 3) * HWD + (tap % 3);
+            if (tap == 0) load_frags(tapoff, stage, 0, fa[0], fb[0]);  // nothing could be prefetched across the halo switch
+            load_frags(tapoff, stage, 1, fa[1], fb[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0][i], fa[0][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap < 8) load_frags(((tap + 1) / 3) * HWD + ((tap + 1) % 3), (stage + 1) & 3, 0, fa[0], fb[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1][i], fa[1][j], acc[i][j], 0, 0, 0);
+            if (tap < 8) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == 8 && chunk + 1 < nchunks) {
+                __builtin_amdgcn_s_barrier();  // every wave is done with this chunk's halo before the next one replaces it
+                issue_halo(chunk + 1);
+            }
+            stage = (stage + 1) & 3;
+        }
+    }
+
+    // ---- epilogue: accumulators -> fp32 LDS tile -> bias, residual, ReLU, 16-byte NHWC stores
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(floatx4*)(smem + (w * 64 + j * 16 + fr) * EPI_ROW + (i * 16 + fq * 4) * 4) = acc[i][j];
+    __syncthreads();
+    const int cc = tid & 7, r0 = tid >> 3;
+    const int ch = n0 + cc * 8;
+    const floatx4 bias0 = *(const floatx4*)(p.bias + ch), bias1 = *(const floatx4*)(p.bias + ch + 4);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        half8 rv[4];
+        if (p.res) {  // four residual rows of this thread first, then the arithmetic: one exposed latency per four rows
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = (half * 4 + q) * 32 + r0;
+                int y = y0 + m / TW, x = x0 + m % TW;
+                y = y < p.h ? y : p.h - 1;
+                x = x < p.w ? x : p.w - 1;
+                rv[q] = *(const half8*)(p.res + (((int64_t)img * p.res_hp + y + p.res_ring) * p.res_wp + x + p.res_ring) * p.cout + ch);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = (half * 4 + q) * 32 + r0;
+            const int y = y0 + m / TW, x = x0 + m % TW;
+            if (y >= p.h || x >= p.w) continue;
+            floatx4 v0 = *(const floatx4*)(smem + m * EPI_ROW + cc * 32) + bias0;
+            floatx4 v1 = *(const floatx4*)(smem + m * EPI_ROW + cc * 32 + 16) + bias1;
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[q][e]; v1[e] += (float)rv[q][4 + e]; }
+            }
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hv[e] = (half_t)((p.relu && v0[e] < 0.f) ? 0.f : v0[e]);
+                hv[4 + e] = (half_t)((p.relu && v1[e] < 0.f) ? 0.f : v1[e]);
+            }
+            *(half8*)(p.out + (((int64_t)img * p.out_hp + y + p.out_ring) * p.out_wp + x + p.out_ring) * p.cout + ch) = hv;
+        }
+    }
+}
+
+template <int TW>
+int halo64_launch(const HaloParams& p, hipStream_t stream) {
+    constexpr int TH = 256 / TW, HROWS = (TH + 2) * (TW + 2), HBYTES = (HROWS + 7) / 8 * 1024;
+    constexpr int lds = HBYTES + 4 * 64 * 128;
+    static_assert(lds >= 256 * (64 * 4 + 16) && 2 * lds <= 160 * 1024, "epilogue tile fits; two workgroups per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo64_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_halo64_kernel<TW>), dim3(p.n * p.tiles_y * p.tiles_x * p.tiles_n), dim3(256), lds, stream, p);
+    return -(int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // 64 -> 64 channels (ResNet layer1): PERSISTENT workgroups with the whole 3x3x64x64 weight set resident in LDS.
 // Measured on the kernel above (VTD_HALO_STAMPS): an LDS-DMA takes ~2 us to land, so a 3-stage weight ring leaves the matrix
 // pipe waiting on memory 80 % of the time when a K-step is only 0.2 us of MFMA work.  For Cin = Cout = 64 the weights are
@@ -526,6 +714,10 @@ int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream
     if ((int64_t)p.n * c.in_hp * c.in_wp * c.in_c >= (1ll << 31)) return -2202;  // 32-bit element offsets in the loader
     const int th = 256 / tw;
     p.tiles_x = (p.w + tw - 1) / tw; p.tiles_y = (p.h + th - 1) / th; p.tiles_n = bn > 1 ? p.cout / bn : 1;
+    if (bn == 2) {  // second-generation kernel: 64 output channels per workgroup, hand-pipelined (conv_halo64_kernel)
+        p.tiles_n = p.cout / 64;
+        return tw == 16 ? halo64_launch<16>(p, stream) : halo64_launch<32>(p, stream);
+    }
     if (bn == 1) {  // persistent resident-weight variant (cin = cout = 64)
         if (p.cin != 64 || p.cout != 64) return -2201;
         p.tiles_n = 1;

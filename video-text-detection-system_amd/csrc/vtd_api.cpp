@@ -155,6 +155,7 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
 // Tile "configuration" kHaloCfg selects the halo-tile kernel (conv_halo.hip) instead of an implicit-GEMM tile shape.
 static const int kHaloCfg = 100;
 static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 64 -> 64 channels
+static const int kHalo64Cfg = 104;  // second-generation halo kernel: 64 output channels per workgroup, hand-pipelined
 static const int kHeadEntryHalo256Cfg = 103;  // same, 16x16 pixel blocks with 64x64 register tiles (hand-pipelined)
 static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
@@ -170,10 +171,10 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
         if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, cfg == kHeadEntryHalo256Cfg ? 1 : 0, s);
     }
-    if (cfg == kHaloCfg || cfg == kHaloC64Cfg) {
+    if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg) {
         int bn = 0, tw = 0;
         if (!vtd_conv_halo_supported(p, &bn, &tw)) return ERR_GEOMETRY;
-        return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : bn, tw, s);
+        return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : cfg == kHalo64Cfg ? 2 : bn, tw, s);
     }
     return vtd_launch_conv(p, cfg, s);
 }
@@ -250,10 +251,10 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     int hbn = 0, htw = 0;
     if (!rc && halo_enabled() && vtd_conv_halo_supported(p, &hbn, &htw)) {
         const char* force = std::getenv("VTD_FORCE_HALO");  // tests: 1 = take the halo kernel wherever it applies,
-        if (force && (force[0] == '1' || force[0] == '2')) best = 1e30f;  // 2 = and its persistent 64->64 variant
-        for (int variant = 0; variant < 2 && !rc; ++variant) {
-            if (variant == 1 && !vtd_conv_halo_c64_supported(p, htw)) break;
-            const int bn = variant ? 1 : hbn;
+        if (force && (force[0] == '1' || force[0] == '2' || force[0] == '3')) best = 1e30f;  // 2 = and its persistent 64->64 variant, 3 = the hand-pipelined 64-channel kernel
+        for (int variant = 0; variant < 3 && !rc; ++variant) {
+            if (variant == 1 && !vtd_conv_halo_c64_supported(p, htw)) continue;
+            const int bn = variant == 1 ? 1 : variant == 2 ? 2 : hbn;
             if ((rc = vtd_launch_conv_halo(p, bn, htw, s))) break;
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_conv_halo(p, bn, htw, s);
@@ -261,7 +262,8 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
             if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            if (!rc && (ms < best || (variant && force && force[0] == '2'))) { best = ms; best_id = variant ? kHaloC64Cfg : kHaloCfg; }
+            const int vid = variant == 1 ? kHaloC64Cfg : variant == 2 ? kHalo64Cfg : kHaloCfg;
+            if (!rc && (ms < best || (variant == 1 && force && force[0] == '2') || (variant == 2 && force && force[0] == '3'))) { best = ms; best_id = vid; }
         }
     }
     (void)hipEventDestroy(e0);
@@ -1244,9 +1246,9 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
         else if (cfg == kHeadEntryHaloCfg)
             std::snprintf(name, name_cap, "head_entry_halo M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
                           "next slot)", c.ho * c.wo, c.cout, c.K);
-        else if (cfg == kHaloCfg || cfg == kHaloC64Cfg)
-            std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : "", c.ho * c.wo,
-                          c.cout, c.K);
+        else if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg)
+            std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : cfg == kHalo64Cfg ? "64" : "",
+                          c.ho * c.wo, c.cout, c.K);
         else
             std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 12) ? kTile[cfg] : "default",
                           c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
