@@ -710,7 +710,9 @@ int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream
     p.res_hp = c.res_hp; p.res_wp = c.res_wp; p.res_ring = c.res_ring;
     p.relu = (c.flags & EPI_RELU) ? 1 : 0;
     p.stamps = nullptr;
-    if (c.in_y0 != c.in_x0 || c.K != 9 * c.in_c || c.out_c != c.cout || p.n <= 0) return -2201;
+    if (c.in_y0 != c.in_x0 || c.in_y0 < 0 || c.K != 9 * c.in_c || c.out_c != c.cout || p.n <= 0 || (c.in_c & 63) || (c.cout & 63) ||
+        (tw != 16 && tw != 32) || c.stride != 1 || c.M != p.n * c.ho * c.wo)
+        return -2201;  // shapes are validated here: a mismatch must never reach a kernel
     if ((int64_t)p.n * c.in_hp * c.in_wp * c.in_c >= (1ll << 31)) return -2202;  // 32-bit element offsets in the loader
     const int th = 256 / tw;
     p.tiles_x = (p.w + tw - 1) / tw; p.tiles_y = (p.h + th - 1) / th; p.tiles_n = bn > 1 ? p.cout / bn : 1;
