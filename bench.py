@@ -45,27 +45,106 @@ def parse():
                     help="PCIe-inclusive variant (not the headline value): every step uploads its batch from pinned host memory "
                          "on an upload stream")
     ap.add_argument("--layers-out", default=None, help="write the per-launch table as JSON to this path")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / aggregation only (gloo, no GPU work): what the CPU test of the N>1 entry runs")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun wrapper: this parent starts the N ranks itself as fresh child processes
+    (one per GPU) and never touches the GPU (it does not even import torch), relays rank 0's JSON line and exits non-zero
+    if any rank does.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is already set and this is
+    not taken."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves the others waiting in a collective: stop them (exact PIDs) instead of hanging with them
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=20))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    reader.join(timeout=5)
+    for line in b"".join(chunks).decode().splitlines():   # the JSON line to stdout, library chatter (gloo banners) to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_run(args, rank, world):
+    """The N>1 control flow without the GPU: rendezvous, barrier, MAX-over-ranks of the elapsed time, one JSON line."""
+    if os.environ.get("VTD_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank dies before the rendezvous
+        raise SystemExit(3)
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        ranks = [(0, 0)]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": 0.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "ranks": ranks, "elapsed_max_s": float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import numpy as np
     import torch
     from vtd_amd import synth, weights
     from vtd_amd.engine import DeviceFrames, detector_profile
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank if torch.cuda.device_count() > 1 else 0)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # backend "nccl" is RCCL on ROCm; VTD_DIST_BACKEND=gloo lets two ranks rehearse the N>1 path on one GPU
         dist.init_process_group(os.environ.get("VTD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
@@ -83,7 +162,7 @@ def main():
     pipe = VideoTextPipeline(use_transformer_ocr=False, backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64
     pipe.detector.model.load_state_dict(sd)
-    rec_sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    rec_sd = weights.margin_crnn_state_dict(11)
     pipe.recognizer.model.load_state_dict(rec_sd)
     eng = pipe.detector.model.engine()
     lib = eng.lib
@@ -203,24 +282,26 @@ def main():
         algo_flops_step = 2.0 * eng.macs_per_frame * B
         traffic = traffic_detail = None
         try:  # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/, FETCH_SIZE x2 corrected)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_per_launch.json")))
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_per_launch.json")))[-1]
+            pmc = json.load(open(pmc_path))
 
             def pick(substr):
                 hits = [v for k, v in pmc.items() if substr in k and v["launches"] >= 3]
                 return max(hits, key=lambda h: h["launches"]) if hits else None
 
-            parts = []
-            if "head_entry_halo" in name:
-                parts = [pick("head_entry_halo_kernel")]
-            elif "classed" in name:
-                parts = [pick("true>")]
-            parts = [v for v in parts if v]
+            # launch-slot description (vtd_api.cpp) -> device kernel symbol of exactly that variant
+            symbol = next((sym for key, sym in (("head_entry_halo256", "head_entry_halo256_kernel("),
+                                                ("head_entry_halo ", "head_entry_halo_kernel<"),
+                                                ("classed", "true>(")) if key in name), None)
+            parts = [v for v in [pick(symbol) if symbol else None] if v]
             if parts:
                 rd = sum(v["hbm_read_MB_corrected_x2"] for v in parts)
                 wr = sum(v["hbm_write_MB"] for v in parts)
                 traffic = int((rd + wr) * 1e6)
                 traffic_detail = {"hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2),
-                                  "source": "profiles/r01_pmc_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                  "kernel_symbol": symbol,
+                                  "source": "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                             "median over launches, FETCH_SIZE x2 per the gfx950 note)"}
         except Exception:
             traffic = traffic_detail = None

@@ -115,15 +115,21 @@ def _lstm_dir(seq, w_ih, w_hh, b_ih, b_hh, reverse):
 
 
 @torch.no_grad()
-def crnn_forward(x, sd, return_cnn=False):
+def crnn_forward(x, sd, return_cnn=False, return_layers=False):
+    """return_cnn: (logits, cnn features); return_layers: (logits, cnn features, [h0, h1]) with the two LSTM layer
+    outputs as [B,31,512] (forward units first, as nn.LSTM concatenates them)."""
     feat = crnn_cnn(x, sd)
     b, c, h, w = feat.shape
     seq = feat.reshape(b, c * h, w).permute(0, 2, 1)
+    layers = []
     for layer in range(2):
         fw = _lstm_dir(seq, sd[f"rnn.weight_ih_l{layer}"], sd[f"rnn.weight_hh_l{layer}"],
                        sd[f"rnn.bias_ih_l{layer}"], sd[f"rnn.bias_hh_l{layer}"], False)
         bw = _lstm_dir(seq, sd[f"rnn.weight_ih_l{layer}_reverse"], sd[f"rnn.weight_hh_l{layer}_reverse"],
                        sd[f"rnn.bias_ih_l{layer}_reverse"], sd[f"rnn.bias_hh_l{layer}_reverse"], True)
         seq = torch.cat([fw, bw], dim=2)
+        layers.append(seq)
     logits = seq @ sd["classifier.weight"].t() + sd["classifier.bias"]
+    if return_layers:
+        return logits, feat, layers
     return (logits, feat) if return_cnn else logits

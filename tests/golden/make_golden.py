@@ -122,19 +122,64 @@ def main():
     np.savez_compressed(os.path.join(HERE, "decode_inputs.npz"), **dec_in)
     json.dump(dec_out, open(os.path.join(HERE, "decode_expected.json"), "w"), indent=1)
 
-    # ---- G1 CRNN logits + conv-stack tap
-    sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
+    # ---- G1 CRNN logits + taps (conv stack, both LSTM layers) on BN-calibrated, amplified weights: with torch's default
+    # init the CRNN ignores its input (round-1 review), so the golden would not discriminate anything
+    from vtd_amd import synth, weights
+    from oracle import cstages
+    sd = weights.calibrated_crnn_state_dict(11)
     ref_crnn = rec.CRNN(97).eval()
     ref_crnn.load_state_dict(sd, strict=True)
     out["crnn_keys"] = {k: list(v.shape) for k, v in ref_crnn.state_dict().items()}
-    g = torch.Generator().manual_seed(21)
-    x = torch.rand(4, 3, 32, 128, generator=g)
+    x = torch.from_numpy(synth.glyph_batch(21, 8))
+
+    def lstm_layers(model, feat):
+        """layer outputs of the reference's nn.LSTM: layer 1 through a 1-layer nn.LSTM holding the same l0 tensors"""
+        b, c, h, w = feat.shape
+        seq = feat.view(b, c * h, w).permute(0, 2, 1)
+        l0 = torch.nn.LSTM(512, 256, 1, batch_first=True, bidirectional=True)
+        l0.load_state_dict({k: v for k, v in model.rnn.state_dict().items() if "_l0" in k}, strict=True)
+        return l0(seq)[0], model.rnn(seq)[0]
+
     with torch.no_grad():
         logits = ref_crnn(x)
-        feat = ref_crnn.cnn(x[:1])
-    np.savez_compressed(os.path.join(HERE, "crnn_g1.npz"), logits=logits.numpy(), cnn_b0=feat.numpy())
-    out["crnn_g1"] = {"weights_seed": 11, "input_seed": 21, "input": "torch.rand(4,3,32,128, generator=manual_seed(21))",
-                      "logits": stats(logits), "cnn": stats(feat)}
+        feat = ref_crnn.cnn(x)
+        h0, h1 = lstm_layers(ref_crnn, feat)
+        zero_logits = ref_crnn(torch.zeros(1, 3, 32, 128))
+    np.savez_compressed(os.path.join(HERE, "crnn_g1.npz"), logits=logits.numpy(), cnn=feat.numpy().astype(np.float16),
+                        h0=h0.numpy().astype(np.float16), h1=h1.numpy().astype(np.float16), zero_logits=zero_logits.numpy())
+    out["crnn_g1"] = {"weights": "vtd_amd.weights.calibrated_crnn_state_dict(11)", "input": "vtd_amd.synth.glyph_batch(21, 8)",
+                      "taps": "cnn [8,512,1,31], h0/h1 [8,31,512] stored as float16 (tolerances in the tests are far above 2^-11)",
+                      "logits": stats(logits), "cnn": stats(feat), "h0": stats(h0), "h1": stats(h1)}
+
+    # ---- G1m margin-carrier CRNN: logits + the strings the reference's own softmax + _decode_prediction produce
+    msd = weights.margin_crnn_state_dict(11)
+    ref_crnn.load_state_dict(msd, strict=True)
+    crops = []
+    for seed in (100, 101):
+        frame, rects = synth.text_frame(seed)
+        for r in rects:
+            hw = 0.5 * (abs(np.cos(r["angle"])) * r["length"] + abs(np.sin(r["angle"])) * r["thick"])
+            hh = 0.5 * (abs(np.sin(r["angle"])) * r["length"] + abs(np.cos(r["angle"])) * r["thick"])
+            x1, x2 = int(max(0, r["cx"] - hw)), int(min(frame.shape[1], r["cx"] + hw))
+            y1, y2 = int(max(0, r["cy"] - hh)), int(min(frame.shape[0], r["cy"] + hh))
+            crops.append(cstages.cv_resize_linear(frame[y1:y2, x1:x2], 128, 32))
+    crops += [synth.glyph_crop(300 + i, 32, 128) for i in range(4)]
+    xu8 = np.stack(crops)
+    xm = torch.from_numpy(xu8).permute(0, 3, 1, 2).float() / 255.0
+    with torch.no_grad():
+        mlogits = ref_crnn(xm)
+        mh0, mh1 = lstm_layers(ref_crnn, ref_crnn.cnn(xm))
+        probs = torch.softmax(mlogits, dim=2)
+    decoded = [tr._decode_prediction(p) for p in probs]
+    car = [0, 1, 2, 256, 257, 258]  # the carrier units of both directions (weights.margin_crnn_state_dict)
+    np.savez_compressed(os.path.join(HERE, "crnn_g1_margin.npz"), x_u8=xu8, logits=mlogits.numpy(),
+                        h0_carrier=mh0[:, :, car].numpy(), h1_carrier=mh1[:, :, car].numpy())
+    top2 = torch.sort(probs, dim=2).values[..., -2:]
+    out["crnn_g1_margin"] = {"weights": "vtd_amd.weights.margin_crnn_state_dict(11)",
+                             "input": "x_u8 [n,32,128,3] uint8 BGR crops (rotated-rectangle crops of synth.text_frame(100..101) "
+                                      "resized with the oracle's INTER_LINEAR + 4 glyph crops); fed as /255 CHW",
+                             "min_top1_margin": float((top2[..., 1] - top2[..., 0]).min()),
+                             "decoded": [{"text": t, "confidence": c} for t, c in decoded]}
 
     # ---- G2 DBHead probability branch
     head_sd = mynets.seeded_state_dict(lambda: mynets.DBHead(256), seed=12)

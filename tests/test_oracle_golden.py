@@ -50,16 +50,52 @@ def test_state_dict_key_contract(golden_dir):
     assert sum(int(np.prod(s)) for k, s in m["crnn_keys"].items() if "num_batches" not in k and "running" not in k) == 8758113
 
 
-def test_g1_crnn_logits(golden_dir):
+def test_g1_crnn_logits_and_lstm_taps(golden_dir):
+    """G1: the reference's CRNN on BN-calibrated weights and glyph crops -- logits, conv features and both LSTM layer
+    outputs.  The fixture is only worth something if the network looks at its input: checked first."""
+    from vtd_amd import synth, weights
     g = _load(golden_dir, "crnn_g1.npz")
-    sd = mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11)
-    x = torch.rand(4, 3, 32, 128, generator=torch.Generator().manual_seed(21))
-    logits, feat = onets.crnn_forward(x, sd, return_cnn=True)
-    assert logits.shape == (4, 31, 97) and feat.shape == (4, 512, 1, 31)
-    np.testing.assert_allclose(feat[:1].numpy(), g["cnn_b0"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-5)
-    # batch-size independence of the restatement (B=1 slice of the same inputs)
-    np.testing.assert_allclose(onets.crnn_forward(x[2:3], sd).numpy(), g["logits"][2:3], rtol=0, atol=2e-5)
+    sd = weights.calibrated_crnn_state_dict(11)
+    x = torch.from_numpy(synth.glyph_batch(21, 8))
+    ref = g["logits"]
+    pair = min(float(np.abs(ref[i] - ref[j]).max()) for i in range(8) for j in range(i))
+    assert pair > 1.0 and float(np.abs(ref - g["zero_logits"]).max(axis=(1, 2)).min()) > 1.0   # input-dependent by O(1)
+    logits, feat, (h0, h1) = onets.crnn_forward(x, sd, return_layers=True)
+    assert logits.shape == (8, 31, 97) and feat.shape == (8, 512, 1, 31) and h0.shape == h1.shape == (8, 31, 512)
+    np.testing.assert_allclose(logits.numpy(), ref, rtol=0, atol=1e-4 * pair)
+    for name, got in (("cnn", feat), ("h0", h0), ("h1", h1)):   # stored as float16: half an ulp of the stored value
+        want = g[name].astype(np.float32)
+        np.testing.assert_allclose(got.numpy(), want, rtol=6e-4, atol=1e-5, err_msg=name)
+    # batch-size independence of the restatement and the negative control's own golden
+    np.testing.assert_allclose(onets.crnn_forward(x[2:3], sd).numpy(), ref[2:3], rtol=0, atol=1e-4 * pair)
+    np.testing.assert_allclose(onets.crnn_forward(torch.zeros(1, 3, 32, 128), sd).numpy(), g["zero_logits"], rtol=0, atol=1e-4 * pair)
+
+
+def test_g1m_margin_crnn_strings(golden_dir):
+    """G1m: margin-carrier weights -- the oracle reproduces the strings the reference's softmax + _decode_prediction gave,
+    the fixture is well-posed (top-1 margin) and diverse, and the carrier units sit on their saturated levels."""
+    from vtd_amd import weights
+    g = _load(golden_dir, "crnn_g1_margin.npz")
+    exp = _manifest(golden_dir)["crnn_g1_margin"]["decoded"]
+    sd = weights.margin_crnn_state_dict(11)
+    x = torch.from_numpy(g["x_u8"]).permute(0, 3, 1, 2).float() / 255.0
+    logits, _, (h0, h1) = onets.crnn_forward(x, sd, return_layers=True)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-4)
+    car = [0, 1, 2, 256, 257, 258]
+    np.testing.assert_allclose(h0[:, :, car].numpy(), g["h0_carrier"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(h1[:, :, car].numpy(), g["h1_carrier"], rtol=0, atol=1e-5)
+    lv = np.abs(g["h1_carrier"])
+    assert np.all(np.abs(lv - weights.TANH1) < 2e-3)          # every layer-2 carrier output is saturated +-tanh(1)
+    probs = torch.softmax(logits, dim=2).numpy()
+    top2 = np.sort(probs, axis=2)[..., -2:]
+    assert float((top2[..., 1] - top2[..., 0]).min()) >= 0.9
+    got = [opipe.decode_prediction(p) for p in probs]
+    assert [t for t, _ in got] == [e["text"] for e in exp]
+    assert max(abs(c - e["confidence"]) for (_, c), e in zip(got, exp)) <= 1e-6
+    assert len({e["text"] for e in exp}) >= 5 and all(e["text"] for e in exp)
+    # the live-class table: code 0 is the blank, '<unk>' is live (its quirk is exercised by real strings)
+    live = weights.margin_crnn_live_classes(11)
+    assert live[0] == 0 and len(set(live)) == 64 and 96 in live
 
 
 def test_g2_dbhead(golden_dir):

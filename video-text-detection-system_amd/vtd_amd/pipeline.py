@@ -52,57 +52,97 @@ class VideoTextPipeline:
         self.confidence_threshold = confidence_threshold
         self.batch_size = batch_size
         self.executor = ThreadPoolExecutor(max_workers=4)
+        self._device_index = torch.cuda.current_device() if torch.cuda.is_available() else None
 
     # ---------------------------------------------------------------------------------- video loop
     async def process_video(self, video_path: str, output_dir: str, progress_callback=None) -> Dict[str, Any]:
+        """pipeliine.py:34-91.  When torch.distributed is initialised with W > 1 ranks (one process per GPU) the loop runs in
+        its rank-aware mode (BASELINE configs[3]): sampled frame i belongs to rank i mod W, every rank pushes
+        only its own frames through its device pipeline, and once per round of W x batch_size frames the ranks exchange
+        their finished results in ONE all_gather of a padded block (vtd_amd/shard.py, RCCL on its own stream).  Rank 0
+        returns the merged result ordered by frame number -- identical to the single-GPU result; the other ranks return
+        the same summary / video_info with an empty 'results' list."""
         try:
+            from . import shard
             start_time = time.time()
+            self._bind_device()
             video_info = self.video_processor.get_video_info(video_path)
             frames = self.video_processor.extract_frames_generator(video_path)
             all_results: List[Dict] = []
             frame_count = 0
             total_frames = video_info.get("frame_count", 0)
             pending_frames, pending_info = [], []
+            world, rank, gather = 1, 0, None
+            if shard.is_distributed() and os.environ.get("VTD_SHARD_VIDEO", "1") != "0":
+                import torch.distributed as dist
+                world, rank = dist.get_world_size(), dist.get_rank()
+                gather = shard.ResultGather()
+            seen = 0          # frames of the current round seen by every rank (W x batch_size closes a round)
 
             loop = asyncio.get_event_loop()
 
-            async def flush():
+            async def flush(last=False):
                 # Batches of equally sized frames ride the three-deep device pipeline (upload stream -> detector -> post-process /
                 # recogniser streams, see _pipeline_push): results come back one or two batches later, in frame order.  Anything
                 # else drains the pipeline first and takes the reference-shaped route.
-                nonlocal frame_count
-                if self._fast_path_ok(pending_frames):
-                    done = await loop.run_in_executor(self.executor, self._pipeline_push, list(pending_frames), list(pending_info))
-                else:
-                    done = await loop.run_in_executor(self.executor, self._pipeline_drain)
-                    done += await self._process_frame_batch(pending_frames, pending_info, output_dir)
-                all_results.extend(done)
-                frame_count += len(pending_frames)
+                nonlocal frame_count, seen
+                done = []
+                if pending_frames:
+                    if self._fast_path_ok(pending_frames):
+                        done = await loop.run_in_executor(self.executor, self._pipeline_push, list(pending_frames), list(pending_info))
+                    else:
+                        done = await loop.run_in_executor(self.executor, self._pipeline_drain)
+                        done += await self._process_frame_batch(pending_frames, pending_info, output_dir)
+                if last:
+                    done += await loop.run_in_executor(self.executor, self._pipeline_drain)
+                if gather is None:
+                    all_results.extend(done)
+                    frame_count += len(pending_frames)
+                else:  # every rank enters the collective once per round, whatever it carries
+                    await loop.run_in_executor(self.executor, gather.submit, done)
+                    merged = await loop.run_in_executor(self.executor, gather.retire, 0 if last else 1)
+                    if rank == 0:
+                        all_results.extend(merged)
+                    frame_count += seen
+                    seen = 0
                 pending_frames.clear()
                 pending_info.clear()
 
             async for frame, frame_number, timestamp in frames:
-                pending_frames.append(frame)
-                pending_info.append((frame_number, timestamp))
-                if len(pending_frames) >= self.batch_size:
+                if gather is None or (frame_count + seen) % world == rank:
+                    pending_frames.append(frame)
+                    pending_info.append((frame_number, timestamp))
+                seen += 1
+                if (len(pending_frames) >= self.batch_size) if gather is None else (seen >= world * self.batch_size):
                     await flush()
                     if progress_callback:
                         progress = frame_count / total_frames if total_frames > 0 else 0
                         await progress_callback(progress, frame_count, total_frames)
-            if pending_frames:
-                await flush()
-            all_results.extend(await loop.run_in_executor(self.executor, self._pipeline_drain))
+            await flush(last=True)
+            if gather is not None:
+                all_results.sort(key=lambda fr: fr["frame_number"])
             processing_time = time.time() - start_time
-            return {"status": "success", "results": all_results,
-                    "summary": self._generate_summary(all_results, processing_time, frame_count), "video_info": video_info}
+            out = {"status": "success", "results": all_results,
+                   "summary": self._generate_summary(all_results, processing_time, frame_count), "video_info": video_info}
+            if gather is not None:
+                out["shard"] = {"rank": rank, "world_size": world}
+            return out
         except Exception as e:
             logger.error(f"Video processing failed: {e}")
             self._abandon_pipeline()
             return {"status": "failed", "error": str(e), "results": []}
 
+    def _bind_device(self):
+        """Executor threads start on HIP device 0 whatever the constructing thread selected: re-select this pipeline's GPU
+        (one process per GPU; LOCAL_RANK picks it) at every thread entry."""
+        dev = getattr(self, "_device_index", None)
+        if dev is not None and torch.cuda.is_available():
+            torch.cuda.set_device(dev)
+
     # ---- device pipeline of the video loop: batch i uploads and detects while batch i-1 is recognised and batch i-2 is collected
     def _pipeline_push(self, frames, frame_info) -> List[Dict]:
         from .engine import PINNED, DeviceFrames
+        self._bind_device()
         if getattr(self, "_inflight", None) is None:
             self._inflight = []
         if getattr(self, "_upload", None) is None:
@@ -133,6 +173,7 @@ class VideoTextPipeline:
         return res
 
     def _pipeline_drain(self) -> List[Dict]:
+        self._bind_device()
         out = []
         while getattr(self, "_inflight", None):
             out += self._retire(self._inflight.pop(0))
@@ -229,6 +270,7 @@ class VideoTextPipeline:
 
     def _batched_device_pass(self, frames, frame_info) -> List[Dict]:
         from .engine import DeviceFrames
+        self._bind_device()
         results = []
         cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
         for start in range(0, len(frames), cap):

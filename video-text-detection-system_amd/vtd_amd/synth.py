@@ -67,3 +67,40 @@ def margin_prob_map(seed, h=640, w=640, n_boxes=8, lo=0.1, hi=0.9):
         cover = np.maximum(cover, c)
         placed += 1
     return (lo + (hi - lo) * cover).astype(np.float32)
+
+
+def glyph_crop(seed, height=None, width=None, noise_sigma=4.0):
+    """One text-line-like crop (uint8 BGR, gray): white ground with dark vertical / horizontal strokes of random
+    size and position plus N(0,4) noise.  Content differs strongly from seed to seed, which is what the recogniser's
+    tensor-level parity tests need (uniform-noise images all look alike to a CRNN)."""
+    rng = np.random.default_rng(seed)
+    h = int(rng.integers(20, 60)) if height is None else height
+    w = int(rng.integers(60, 400)) if width is None else width
+    img = np.full((h, w), 255.0, np.float32)
+    x = int(rng.integers(2, 10))
+    while x < w - 6:
+        sw = int(rng.integers(2, 7))
+        kind = int(rng.integers(0, 4))
+        y0 = int(rng.integers(0, max(1, h // 3)))
+        y1 = int(rng.integers(2 * h // 3, h))
+        if kind == 0:
+            img[y0:y1, x:x + sw] = 0
+        elif kind == 1:
+            img[y0:y0 + sw, x:x + 3 * sw] = 0
+        elif kind == 2:
+            img[y1 - sw:y1, x:x + 3 * sw] = 0
+            img[y0:y1, x:x + sw] = 0
+        else:
+            mid = (y0 + y1) // 2
+            img[mid:mid + sw, x:x + 3 * sw] = 0
+        x += int(rng.integers(6, 20))
+    img += rng.normal(0.0, noise_sigma, img.shape).astype(np.float32)
+    g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+
+
+def glyph_batch(seed, n):
+    """[n,3,32,128] float32 CRNN inputs in the reference's format (text_recognizer.py:118-119: BGR/255, CHW) made of
+    32x128 glyph crops (no resize involved)."""
+    x = np.stack([glyph_crop(seed * 1000 + i, 32, 128) for i in range(n)])
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32) / np.float32(255.0)

@@ -132,3 +132,176 @@ def margin_detector_state_dict(backbone="resnet18", seed=0, gain=16.0):
         w6[0, 0] = gain
         sd[head + "6.bias"][0] = -gain / 2.0
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CRNN fixtures.  With torch's default init the CRNN ignores its input: every conv shrinks the signal while the
+# (uncalibrated) BatchNorm statistics and biases stay O(1), so logits of two different crops differ by ~1e-5 and
+# every crop decodes to the same string.  Two generators fix that (fixture generation only: plain torch CPU ops on
+# a 24-crop calibration batch, never on the product path):
+#
+# * ``calibrated_crnn_state_dict``  default init, then every BatchNorm's running statistics are set to the actual
+#   batch statistics of its input on seeded glyph crops (what training would have left there) and the LSTM input /
+#   classifier weights are scaled up.  Logits then move by O(1) between crops: tensor-level tolerance tests on
+#   logits and taps become discriminating (tolerance << inter-input variation).
+#
+# * ``margin_crnn_state_dict``  the calibrated dense network plus a *carrier* that takes every decision with margin
+#   (the CRNN analogue of margin_detector_state_dict).  fp16-vs-fp32 string identity is otherwise ill-posed: a
+#   97-way arg-max at 31 timesteps of a random dense network has a near-tie (gap below the fp16 error) in >10 % of
+#   crops whatever the gain.  Carrier path (gray crops, i.e. B=G=R=n/255):
+#     conv1  ch0 = B/4+G/4+R/2 = n/255               (weights exact in fp16)      pool: max keeps the lattice
+#     conv2  ch0 = t = relu(255*x - 127.5)           decision n >= 128, margin 0.5 on a value known to 1e-3
+#     conv3  ch0 = relu(t), ch1 = relu(t - 0.5)      conv4  ch0 = 2*ch0 - 2*ch1 in {0} u [0.9,1]
+#     conv5/6 pass; the (2,1) pools leave two rows = "top half has ink", "bottom half has ink" per 4-px column
+#     conv7  (2x2, no pad) ch0 = row 0, ch1 = row 1   ->  feature bits T_t, B_t for t = 0..30
+#     LSTM layer 1  forward: u0 = T_t, u1 = rising edge of T (reads h[u0] of step t-1 through W_hh)
+#                   reverse: u0 = B_t, u1 = rising edge of B in reverse time
+#     LSTM layer 2  forward: u0 = T, u1 = edge, u2 = latch "an edge was seen so far" (self-recurrent through W_hh)
+#                   reverse: same for B in reverse time
+#     classifier    the six saturated +-0.76 bits select one of 64 live classes by codeword (Hamming margin 2*G);
+#                   the other 33 classes get a large negative bias; the dense units add O(0.1) on top.
+#   Every gate pre-activation of a carrier unit is >= 0.8*GATE away from 0, so strings depend on gate order, time
+#   direction, recurrence and the time index of every output, but not on rounding.
+
+_CRNN_CONV = ((0, 1, 1, "p22"), (4, 5, 1, "p22"), (8, 9, 1, None), (11, 12, 1, "p21"), (15, 16, 1, None),
+              (18, 19, 1, "p21"), (22, 23, 0, None))
+GATE = 16.0
+TANH1 = 0.7615941559557649  # tanh(1): |h| of a saturated pass-through unit
+
+
+def _crnn_calibrate(sd, x, keep=None):
+    """Set each BN's running stats to the batch statistics of its input on x; channels listed in keep[bn_idx] keep
+    theirs (carrier channels)."""
+    import torch.nn.functional as F
+    y = x
+    for ci, bi, pad, pool in _CRNN_CONV:
+        z = F.conv2d(y, sd[f"cnn.{ci}.weight"], sd[f"cnn.{ci}.bias"], 1, pad)
+        mean, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False).clamp_min(1e-4)
+        for ch in (keep or {}).get(bi, ()):
+            mean[ch], var[ch] = sd[f"cnn.{bi}.running_mean"][ch], sd[f"cnn.{bi}.running_var"][ch]
+        sd[f"cnn.{bi}.running_mean"], sd[f"cnn.{bi}.running_var"] = mean, var
+        y = F.relu(F.batch_norm(z, mean, var, sd[f"cnn.{bi}.weight"], sd[f"cnn.{bi}.bias"], False, 0.0, 1e-5))
+        if pool == "p22":
+            y = F.max_pool2d(y, 2, 2)
+        elif pool == "p21":
+            y = F.max_pool2d(y, (2, 1), (2, 1))
+    return sd
+
+
+def _calibration_batch(seed):
+    from . import synth
+    return torch.from_numpy(synth.glyph_batch(7000 + seed, 24))
+
+
+def calibrated_crnn_state_dict(seed=0, vocab_size=97, ih_gain=2.0, cls_gain=8.0):
+    sd = nets.seeded_state_dict(lambda: nets.CRNN(vocab_size), seed)
+    for k in sd:
+        if k.startswith("rnn.weight_ih"):
+            sd[k] = sd[k] * ih_gain
+    sd["classifier.weight"] = sd["classifier.weight"] * cls_gain
+    with torch.no_grad():
+        return _crnn_calibrate(sd, _calibration_batch(seed))
+
+
+def margin_crnn_live_classes(seed=0, vocab_size=97):
+    """code (6 bits: T, B, edgeF, edgeR, latchF, latchR) -> class id.  Code 0 (no ink, nothing seen) is the blank;
+    the 63 others map to a seeded choice of distinct ids from 1..vocab-1 that always contains '<unk>' (= vocab-1)."""
+    g = torch.Generator().manual_seed(seed + 4242)
+    ids = (torch.randperm(vocab_size - 2, generator=g)[:62] + 1).tolist() + [vocab_size - 1]
+    order = torch.randperm(63, generator=g).tolist()
+    return [0] + [ids[i] for i in order]
+
+
+def margin_crnn_state_dict(seed=0, vocab_size=97, cls_gain=3.0):
+    sd = nets.seeded_state_dict(lambda: nets.CRNN(vocab_size), seed)
+    for k in sd:
+        if k.startswith("rnn.weight_ih"):
+            sd[k] = sd[k] * 2.0
+    sd["classifier.weight"] = sd["classifier.weight"] * 0.5
+
+    def conv_carrier(ci, bi, ch, taps, bias=0.0, in_carriers=()):
+        w = sd[f"cnn.{ci}.weight"]
+        w[ch].zero_()
+        for cin, r, s, val in taps:
+            w[ch, cin, r, s] = val
+        sd[f"cnn.{ci}.bias"][ch] = bias
+        _bn_identity(sd, f"cnn.{bi}", ch)
+
+    def blind(ci, carriers_out, carriers_in):
+        """dense output channels do not read the carrier input channels"""
+        w = sd[f"cnn.{ci}.weight"]
+        dense = [c for c in range(w.shape[0]) if c not in carriers_out]
+        for cin in carriers_in:
+            w[dense, cin] = 0.0
+
+    conv_carrier(0, 1, 0, [(0, 1, 1, 0.25), (1, 1, 1, 0.25), (2, 1, 1, 0.5)])
+    conv_carrier(4, 5, 0, [(0, 1, 1, 255.0)], bias=-127.5)
+    blind(4, (0,), (0,))
+    conv_carrier(8, 9, 0, [(0, 1, 1, 1.0)])
+    conv_carrier(8, 9, 1, [(0, 1, 1, 1.0)], bias=-0.5)
+    blind(8, (0, 1), (0,))
+    conv_carrier(11, 12, 0, [(0, 1, 1, 2.0), (1, 1, 1, -2.0)])
+    blind(11, (0,), (0, 1))
+    conv_carrier(15, 16, 0, [(0, 1, 1, 1.0)])
+    blind(15, (0,), (0,))
+    conv_carrier(18, 19, 0, [(0, 1, 1, 1.0)])
+    blind(18, (0,), (0,))
+    conv_carrier(22, 23, 0, [(0, 0, 0, 1.0)])
+    conv_carrier(22, 23, 1, [(0, 1, 0, 1.0)])
+    blind(22, (0, 1), (0,))
+    keep = {1: (0,), 5: (0,), 9: (0, 1), 12: (0,), 16: (0,), 19: (0,), 23: (0, 1)}
+    with torch.no_grad():
+        _crnn_calibrate(sd, _calibration_batch(seed), keep)
+
+    H = 256
+
+    def unit(layer, rev, u, g_in=(), g_rec=(), g_bias=0.0, n_car_in=()):
+        """Carrier LSTM unit u: input and output gates open, forget gate closed, candidate g = tanh(GATE * (sum of
+        g_in[(feature, coef)] + sum of g_rec[(unit, coef)] + g_bias))."""
+        suf = f"_l{layer}" + ("_reverse" if rev else "")
+        w_ih, w_hh = sd["rnn.weight_ih" + suf], sd["rnn.weight_hh" + suf]
+        b_ih, b_hh = sd["rnn.bias_ih" + suf], sd["rnn.bias_hh" + suf]
+        for gate, b in ((0, GATE), (1, -GATE), (2, GATE * g_bias), (3, GATE)):
+            row = gate * H + u
+            w_ih[row].zero_()
+            w_hh[row].zero_()
+            b_ih[row], b_hh[row] = b, 0.0
+        for feat, coef in g_in:
+            w_ih[2 * H + u, feat] = GATE * coef
+        for ru, coef in g_rec:
+            w_hh[2 * H + u, ru] = GATE * coef
+
+    def blind_rnn(layer, rev, units, feats):
+        suf = f"_l{layer}" + ("_reverse" if rev else "")
+        dense = torch.ones(4 * H, dtype=torch.bool)
+        for u in units:
+            dense[[u, H + u, 2 * H + u, 3 * H + u]] = False
+        w_ih, w_hh = sd["rnn.weight_ih" + suf], sd["rnn.weight_hh" + suf]
+        for f in feats:
+            w_ih[dense, f] = 0.0
+        for u in units:
+            w_hh[dense, u] = 0.0
+
+    s = 1.0 / TANH1
+    for rev, feat in ((False, 0), (True, 1)):
+        unit(0, rev, 0, g_in=[(feat, 2.0)], g_bias=-1.0)                              # ink bit: +-1 -> h = +-tanh(1)
+        unit(0, rev, 1, g_in=[(feat, 4.0)], g_rec=[(0, -4.0 * s)], g_bias=-5.0)        # rising edge (none at step 0)
+        blind_rnn(0, rev, (0, 1), (0, 1))
+    for rev, base in ((False, 0), (True, H)):
+        unit(1, rev, 0, g_in=[(base + 0, s)])                                          # pass the ink bit
+        unit(1, rev, 1, g_in=[(base + 1, s)])                                          # pass the edge bit
+        unit(1, rev, 2, g_in=[(base + 1, 2.0 * s)], g_rec=[(2, 2.0 * s)], g_bias=1.0)  # latch: edge seen so far
+        blind_rnn(1, rev, (0, 1, 2), (0, 1, H, H + 1))
+
+    live = margin_crnn_live_classes(seed, vocab_size)
+    cw, cb = sd["classifier.weight"], sd["classifier.bias"]
+    carriers = (0, H, 1, H + 1, 2, H + 2)  # T, B, edgeF, edgeR, latchF, latchR
+    cw[:, list(carriers)] = 0.0
+    cb.zero_()
+    dead = torch.ones(vocab_size, dtype=torch.bool)
+    for code, k in enumerate(live):
+        dead[k] = False
+        for b, col in enumerate(carriers):
+            cw[k, col] = cls_gain * s * (1.0 if (code >> b) & 1 else -1.0)
+    cb[dead] = -10.0 * cls_gain
+    return sd
