@@ -1,0 +1,196 @@
+"""Row gaps the round-1 review listed: BASELINE configs[1]/[2] at their full batch of 32, checkpoint ingest through
+load_model (a14), detect() entered from four threads at once (pipeliine.py:32,96-101), a failing batch degrading to empty
+detections instead of failing the video (text_detector.py:139-141)."""
+import asyncio
+import json
+import logging
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import pipeline as opipe
+from vtd_amd import nets as mynets
+from vtd_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe32(hip):
+    from vtd_amd.pipeline import VideoTextPipeline
+    p = VideoTextPipeline(use_transformer_ocr=False, backbone="resnet18", batch_size=32)
+    det_sd = weights.margin_detector_state_dict("resnet18", 0)
+    rec_sd = weights.margin_crnn_state_dict(11)
+    p.detector.model._max_batch = 32
+    p.detector.model.load_state_dict(det_sd)
+    p.recognizer.model.load_state_dict(rec_sd)
+    return p, det_sd, rec_sd
+
+
+def test_batch32_full_pipeline_vs_per_frame_and_oracle(pipe32):
+    """configs[2] at B=32: one 32-frame device pass == 32 one-frame passes (boxes, polygons, strings identical; the per-batch
+    kernel choice may change fp32 summation order, so confidences to 2e-3), and == the oracle on a 4-frame subset."""
+    from vtd_amd.engine import DeviceFrames
+    p, det_sd, rec_sd = pipe32
+    frames = np.stack([synth.text_frame(100 + i)[0] for i in range(32)])
+    assert p.detector.model.engine().max_batch == 32
+    got = p.process_device_batch(DeviceFrames(frames))
+    assert len(got) == 32
+    n_det = 0
+    for i in range(32):
+        one = p.process_device_batch(DeviceFrames(frames[i:i + 1]))[0]["detections"]
+        assert len(one) == len(got[i]["detections"]) > 0
+        for a, b in zip(got[i]["detections"], one):
+            assert a["bbox"] == b["bbox"] and a["polygon"] == b["polygon"] and a["text"] == b["text"]
+            assert abs(a["detection_confidence"] - b["detection_confidence"]) <= 2e-3
+            assert abs(a["recognition_confidence"] - b["recognition_confidence"]) <= 2e-3
+        n_det += len(one)
+    assert n_det >= 200            # ~8 crops per frame: the recogniser ran at its full-size crop count too
+    for i in (0, 7, 19, 31):
+        exp = opipe.process_frame_batch([frames[i]], [(0, 0.0)], det_sd, "resnet18", rec_sd, 0.5)[0]["detections"]
+        assert len(exp) == len(got[i]["detections"])
+        for a, e in zip(got[i]["detections"], exp):
+            assert a["bbox"] == e["bbox"] and a["polygon"] == e["polygon"] and a["text"] == e["text"] != ""
+            assert abs(a["detection_confidence"] - e["detection_confidence"]) <= 2e-3
+            assert abs(a["recognition_confidence"] - e["recognition_confidence"]) <= 2e-3
+
+
+def test_batch32_probability_maps_vs_oracle(hip):
+    """configs[1] at B=32, tensor level with default-init weights (no margin to hide behind): probability maps of a 32-frame
+    forward against the fp32 oracle on four of the frames, max|dp| <= 2e-3."""
+    from vtd_amd.engine import DetectorEngine, DeviceFrames
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    eng = DetectorEngine("resnet18", sd, max_batch=32)
+    try:
+        frames = np.stack([synth.text_frame(500 + i)[0] for i in range(32)])
+        prob = eng.forward(DeviceFrames(frames))["probability"]
+        assert prob.shape == (32, 1, 640, 640)
+        for i in (0, 13, 31):
+            ref = onets.dbnet_forward(opipe.preprocess(frames[i]), sd, "resnet18")["probability"][0, 0].numpy()
+            err = float(np.abs(prob[i, 0].cpu().numpy() - ref).max())
+            print("frame", i, "max|dp|", err)
+            assert err <= 2e-3
+        # and the batch is not 32 copies of one answer
+        assert float((prob[0] - prob[31]).abs().max()) > 1e-2
+    finally:
+        eng.close()
+
+
+def test_load_model_checkpoint_round_trip(hip, tmp_path, caplog):
+    """a14: {'model_state_dict': sd} files written with torch.save, read through load_model (text_detector.py:106-113,
+    text_recognizer.py:93-100): same outputs as feeding the state dict directly; broken files re-raise after logging."""
+    from vtd_amd.detector import TextDetector
+    from vtd_amd.recognizer import TextRecognizer
+    det_sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=31)
+    rec_sd = weights.calibrated_crnn_state_dict(32)
+    torch.save({"model_state_dict": det_sd, "epoch": 3}, tmp_path / "det.pth")
+    torch.save({"model_state_dict": rec_sd}, tmp_path / "rec.pth")
+    x = torch.randn(1, 3, 640, 640, generator=torch.Generator().manual_seed(3))
+    det = TextDetector(str(tmp_path / "det.pth"), backbone="resnet18", max_batch=1)
+    ref = onets.dbnet_forward(x, det_sd, "resnet18")["probability"].numpy()
+    assert float(np.abs(det.model(x)["probability"].cpu().numpy() - ref).max()) <= 2e-3
+    fresh = TextDetector(backbone="resnet18", max_batch=1)          # default init differs, then load_model brings it in line
+    before = fresh.model(x)["probability"].cpu().numpy()
+    assert float(np.abs(before - ref).max()) > 1e-2
+    fresh.load_model(str(tmp_path / "det.pth"))
+    assert float(np.abs(fresh.model(x)["probability"].cpu().numpy() - ref).max()) <= 2e-3
+
+    rec = TextRecognizer(str(tmp_path / "rec.pth"), use_transformer=False, max_crops=8)
+    xr = torch.from_numpy(synth.glyph_batch(5, 4))
+    want = onets.crnn_forward(xr, rec_sd).numpy()
+    pair = min(float(np.abs(want[i] - want[j]).max()) for i in range(4) for j in range(i))
+    assert float(np.abs(rec.model(xr).cpu().numpy() - want).max()) <= pair / 100
+
+    (tmp_path / "garbage.pth").write_bytes(b"not a checkpoint")
+    torch.save({"weights": det_sd}, tmp_path / "nokey.pth")
+    short = {k: v for k, v in det_sd.items() if not k.startswith("head.")}
+    torch.save({"model_state_dict": short}, tmp_path / "short.pth")
+    for name, err in (("garbage.pth", Exception), ("nokey.pth", KeyError), ("short.pth", RuntimeError), ("missing.pth", Exception)):
+        with caplog.at_level(logging.ERROR):
+            with pytest.raises(err):
+                det.load_model(str(tmp_path / name))
+        with pytest.raises(err):
+            rec.load_model(str(tmp_path / name))
+    assert "Failed to load model" in caplog.text
+    # a failed load leaves the detector usable with its previous weights
+    assert float(np.abs(det.model(x)["probability"].cpu().numpy() - ref).max()) <= 2e-3
+
+
+def test_detect_from_four_threads_on_a_fresh_detector(hip):
+    """One TextDetector, four pool threads, mixed frame sizes, engine and post-process workspaces not built yet: results equal
+    the single-thread results (bit-identical boxes; one engine is built, not four)."""
+    from vtd_amd import engine as eng_mod
+    from vtd_amd.detector import TextDetector
+    built = []
+    orig = eng_mod.DetectorEngine.__init__
+
+    def counting(self, *a, **k):
+        built.append(1)
+        return orig(self, *a, **k)
+
+    det = TextDetector(backbone="resnet18", max_batch=4)
+    det.model.load_state_dict(weights.margin_detector_state_dict("resnet18", 0))
+    sizes = [(720, 1280), (480, 640), (1080, 1920), (720, 1280)]
+    frames = [synth.text_frame(40 + i, *sizes[i % 4])[0] for i in range(16)]
+    eng_mod.DetectorEngine.__init__ = counting
+    try:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            got = list(ex.map(lambda f: det.detect(f, 0.5), frames))
+    finally:
+        eng_mod.DetectorEngine.__init__ = orig
+    assert sum(built) == 1
+    want = [det.detect(f, 0.5) for f in frames]
+    assert all(len(w) > 0 for w in want)
+    for g, w in zip(got, want):
+        assert [d["bbox"] for d in g] == [d["bbox"] for d in w]
+        assert [d["polygon"] for d in g] == [d["polygon"] for d in w]
+        assert all(abs(a["confidence"] - b["confidence"]) <= 1e-6 for a, b in zip(g, w))
+
+
+def test_failing_batch_degrades_to_empty_detections(pipe32, tmp_path, caplog):
+    """A batch whose device submission raises yields [] for its frames and the video goes on (the reference's detect()
+    returns [] and continues, text_detector.py:139-141); a recogniser failure keeps the boxes with empty texts
+    (text_recognizer.py:138-140)."""
+    p, _, _ = pipe32
+    frames = np.stack([synth.text_frame(400 + i)[0] for i in range(10)])
+    path = tmp_path / "clip.npy"
+    np.save(path, frames)
+    (tmp_path / "clip.npy.json").write_text(json.dumps({"fps": 10.0}))
+    old_bs, p.batch_size = p.batch_size, 4
+    good = asyncio.run(p.process_video(str(path), str(tmp_path)))
+    calls = {"n": 0}
+    real_submit = p.detector.submit_batch
+
+    def flaky(batch, thr=0.5):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("injected device failure")
+        return real_submit(batch, thr)
+
+    p.detector.submit_batch = flaky
+    try:
+        with caplog.at_level(logging.ERROR):
+            out = asyncio.run(p.process_video(str(path), str(tmp_path)))
+    finally:
+        del p.detector.submit_batch
+    assert out["status"] == "success" and len(out["results"]) == 10
+    assert "injected device failure" in caplog.text
+    for i, (fr, ok) in enumerate(zip(out["results"], good["results"])):
+        assert fr["frame_number"] == i
+        assert fr["detections"] == ([] if 4 <= i < 8 else ok["detections"])
+
+    real_boxes = p.recognizer.submit_boxes
+    p.recognizer.submit_boxes = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected recogniser failure"))
+    try:
+        out = asyncio.run(p.process_video(str(path), str(tmp_path)))
+    finally:
+        del p.recognizer.submit_boxes
+        p.batch_size = old_bs
+    assert out["status"] == "success"
+    for fr, ok in zip(out["results"], good["results"]):
+        assert [d["bbox"] for d in fr["detections"]] == [d["bbox"] for d in ok["detections"]]
+        assert all(d["text"] == "" and d["recognition_confidence"] == 0.0 for d in fr["detections"])
+    assert real_boxes is not None

@@ -7,11 +7,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "vtd_amd", "_lib")
-OUT = os.path.join(OUT_DIR, "libvtd_hip.so")
-OBJ_DIR = os.path.join(HERE, "build")
+# Instrumented variants (extra -D flags: tools/conv_experiment.sh) never overwrite the product library: VTD_LIB_VARIANT=<tag>
+# builds libvtd_hip_<tag>.so from its own object directory, and vtd_amd/_native.py loads it only when VTD_LIB_VARIANT names it.
+VARIANT = os.environ.get("VTD_LIB_VARIANT", "")
+EXTRA = os.environ.get("VTD_EXTRA_HIPCC_FLAGS", "").split()
+if EXTRA and not VARIANT:
+    raise SystemExit("VTD_EXTRA_HIPCC_FLAGS needs VTD_LIB_VARIANT=<tag>: the product library is only ever built with the default flags")
+OUT = os.path.join(OUT_DIR, f"libvtd_hip_{VARIANT}.so" if VARIANT else "libvtd_hip.so")
+OBJ_DIR = os.path.join(HERE, f"build_{VARIANT}" if VARIANT else "build")
 
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-COMMON += os.environ.get("VTD_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DVTD_CONV_EXPERIMENT (tools/conv_experiment.sh)
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + EXTRA
 # the post-process geometry replays float32 arithmetic in a fixed order: no fused multiply-add there
 PER_FILE = {"postprocess.hip": ["-ffp-contract=off"]}
 

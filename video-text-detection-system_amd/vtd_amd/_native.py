@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libvtd_hip.so")
+# VTD_LIB_VARIANT=<tag>: an instrumented build (build_native.py, tools/conv_experiment.sh) living beside the product library
+_VARIANT = os.environ.get("VTD_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "_lib", f"libvtd_hip_{_VARIANT}.so" if _VARIANT else "libvtd_hip.so")
 
 _lib = None
 

@@ -74,8 +74,8 @@ class TextDetector:
         with self._pp_lock:
             pp = self._pp.get(key)
             if pp is None or pp.max_batch < batch:
-                if pp is not None:
-                    pp.close()
+                # a smaller workspace that another thread already fetched stays alive through that thread's reference and is
+                # destroyed with it (PostProcessor.__del__): never close a handle someone may be about to use
                 pp = PostProcessor(max(batch, 1), h, w, self.max_detections)
                 self._pp[key] = pp
             return pp
@@ -146,6 +146,9 @@ class TextDetector:
         from .engine import records_to_dicts
         ticket["event"].synchronize()
         rec, cnt = ticket["rec"].numpy(), ticket["cnt"].numpy()
+        if len(cnt) and int(cnt.max()) > ticket["max_out"]:   # the reference has no cap: say so instead of dropping silently
+            logger.warning(f"{int((cnt > ticket['max_out']).sum())} frame(s) exceed max_detections={ticket['max_out']} "
+                           f"(up to {int(cnt.max())} components); extra detections dropped -- raise TextDetector.max_detections")
         out = [records_to_dicts(rec[i, :min(int(cnt[i]), ticket["max_out"])]) for i in range(len(cnt))]
         PINNED.release(ticket["rec"])
         PINNED.release(ticket["cnt"])

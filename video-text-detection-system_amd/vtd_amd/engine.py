@@ -209,6 +209,10 @@ class PostProcessor:
         with self.lock:
             rec, cnt = self.run_device(prob, orig_w, orig_h, threshold)
             cnt = cnt.cpu().numpy()
+            if int(cnt.max(initial=0)) > self.max_out:
+                import logging
+                logging.getLogger(__name__).warning(f"frame with {int(cnt.max())} components exceeds max_detections={self.max_out}; "
+                                                    "extra detections dropped")
             kmax = int(min(cnt.max(initial=0), self.max_out))
             rec = rec[:, :kmax].cpu().numpy() if kmax else np.zeros((len(cnt), 0, 16), np.int32)
         return [records_to_dicts(rec[i, :min(int(cnt[i]), self.max_out)], debug) for i in range(len(cnt))]

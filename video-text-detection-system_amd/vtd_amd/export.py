@@ -8,8 +8,10 @@
   columns (frame index, timestamp, bbox, confidences, text offsets into one UTF-8 blob) that a database bulk insert or an
   Arrow / Parquet writer takes in one call.
 """
+import csv
 import io
 import logging
+import xml.etree.ElementTree as ET
 from typing import Any, Dict
 
 import numpy as np
@@ -28,62 +30,58 @@ def _rows(results_data):
             yield number, stamp, det
 
 
-def _csv_field(value):
-    """csv.writer's default dialect (excel, QUOTE_MINIMAL, CRLF rows): quote when the text holds a comma, a quote or a line
-    break, double embedded quotes; numbers go through str() (floats by repr, as the csv module does)."""
-    text = "" if value is None else (repr(value) if isinstance(value, float) else str(value))
-    if any(ch in text for ch in ',"\r\n'):
-        return '"' + text.replace('"', '""') + '"'
-    return text
+def _csv_records(results_data):
+    for number, stamp, det in _rows(results_data):
+        box = det.get("bbox", [0, 0, 0, 0])
+        yield (number, stamp, det.get("text", ""), box[0], box[1], box[2], box[3], det.get("detection_confidence", 0.0),
+               det.get("recognition_confidence", 0.0))
 
 
 def export_results_csv(results_data: Dict[str, Any]) -> str:
+    """processing_service.py:59-91: the csv module's default dialect does the quoting (the standard library is the
+    specification here, so it is used, not imitated)."""
     try:
         out = io.StringIO()
-        out.write(",".join(CSV_HEADER) + "\r\n")
-        for number, stamp, det in _rows(results_data):
-            box = det.get("bbox", [0, 0, 0, 0])
-            fields = (number, stamp, det.get("text", ""), box[0], box[1], box[2], box[3], det.get("detection_confidence", 0.0),
-                      det.get("recognition_confidence", 0.0))
-            out.write(",".join(_csv_field(f) for f in fields) + "\r\n")
+        writer = csv.writer(out)
+        writer.writerow(CSV_HEADER)
+        writer.writerows(_csv_records(results_data))
         return out.getvalue()
     except Exception as e:
         logger.error(f"CSV export failed: {e}")
         return ""
 
 
-def _xml_text(s):
-    return s.replace("&", "&amp;").replace("<", "&lt;").replace(">", "&gt;")
+def _build(parent, spec):
+    """spec = (tag, {attr: value}, text or None, [child specs]) -> ElementTree nodes under parent."""
+    tag, attrs, text, children = spec
+    node = ET.Element(tag) if parent is None else ET.SubElement(parent, tag)
+    for key, value in attrs.items():
+        node.set(key, value if isinstance(value, str) else str(value))
+    if text is not None:
+        node.text = text
+    for child in children:
+        _build(node, child)
+    return node
 
 
-def _xml_attr(s):
-    # ElementTree's attribute escaping: markup characters, the double quote, and line breaks / tabs as character references
-    s = _xml_text(s).replace('"', "&quot;")
-    return s.replace("\r", "&#13;").replace("\n", "&#10;").replace("\t", "&#09;")
-
-
-def _element(tag, attrs="", body=None):
-    if body is None or body == "":
-        return f"<{tag}{attrs} />"
-    return f"<{tag}{attrs}>{body}</{tag}>"
+def _object_spec(det):
+    x1, y1, x2, y2 = det.get("bbox", [0, 0, 0, 0])[:4]
+    corners = ((x1, y1), (x2, y1), (x2, y2), (x1, y2))  # clockwise from the top-left corner
+    return ("object", {"transcription": det.get("text", ""),
+                       "detection_confidence": str(det.get("detection_confidence", 0.0)),
+                       "recognition_confidence": str(det.get("recognition_confidence", 0.0))}, None,
+            [("Point", {"x": str(x), "y": str(y)}, None, []) for x, y in corners])
 
 
 def export_results_xml(results_data: Dict[str, Any]) -> str:
+    """processing_service.py:93-137: <video_text_detection><summary/><frames><frame><object><Point/>x4 ... serialised by
+    ElementTree itself (escaping, attribute order = insertion order, ' />' for empty elements)."""
     try:
-        summary = "".join(_element(key, body=_xml_text(str(value))) for key, value in results_data.get("summary", {}).items())
-        frames = []
-        for frame in results_data.get("results", []):
-            objects = []
-            for det in frame.get("detections", []):
-                x1, y1, x2, y2 = det.get("bbox", [0, 0, 0, 0])[:4]
-                points = "".join(f'<Point x="{_xml_attr(str(x))}" y="{_xml_attr(str(y))}" />' for x, y in ((x1, y1), (x2, y1), (x2, y2), (x1, y2)))
-                attrs = (f' transcription="{_xml_attr(det.get("text", ""))}"'
-                         f' detection_confidence="{_xml_attr(str(det.get("detection_confidence", 0.0)))}"'
-                         f' recognition_confidence="{_xml_attr(str(det.get("recognition_confidence", 0.0)))}"')
-                objects.append(_element("object", attrs, points))
-            attrs = f' number="{_xml_attr(str(frame.get("frame_number", 0)))}" timestamp="{_xml_attr(str(frame.get("timestamp", 0.0)))}"'
-            frames.append(_element("frame", attrs, "".join(objects)))
-        return _element("video_text_detection", body=_element("summary", body=summary) + _element("frames", body="".join(frames)))
+        summary = ("summary", {}, None, [(key, {}, str(value), []) for key, value in results_data.get("summary", {}).items()])
+        frames = ("frames", {}, None,
+                  [("frame", {"number": str(fr.get("frame_number", 0)), "timestamp": str(fr.get("timestamp", 0.0))}, None,
+                    [_object_spec(det) for det in fr.get("detections", [])]) for fr in results_data.get("results", [])])
+        return ET.tostring(_build(None, ("video_text_detection", {}, None, [summary, frames])), encoding="unicode")
     except Exception as e:
         logger.error(f"XML export failed: {e}")
         return ""

@@ -14,6 +14,7 @@ Repairs relative to the as-shipped reference: the
 from collections import OrderedDict
 
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -132,27 +133,33 @@ class DBNet(nn.Module):
         self._engine = None
         self._engine_version = -1
         self._version = 0
+        self._engine_lock = threading.Lock()
 
     # any in-place parameter update through the public API invalidates the packed copy
     def load_state_dict(self, state_dict, strict=True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._version += 1
-        return out
+        try:
+            return super().load_state_dict(state_dict, strict=strict, **kw)
+        finally:   # torch copies the matching tensors before it raises on a mismatch: the packed copy is stale either way
+            self._version += 1
 
     def mark_dirty(self):
         self._version += 1
 
     def engine(self):
+        """The native engine for the current parameters, built once under a lock (detect() is entered from four pool threads,
+        pipeliine.py:32,96-101: without it a first mixed-size batch would build four engines).  A replaced engine is only
+        dereferenced, never closed here: a thread still inside it keeps it alive and its handle is destroyed with the last
+        reference."""
         from . import engine as _e
-        if self._engine is None or self._engine_version != self._version:
-            if self._engine is not None:
-                self._engine.close()
-            # VTD_DETECTOR_OPTIONS="fuse_fpn_head=0,fuse_stem_pool=0": build options for A/B measurements (include/vtd.h)
-            opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_DETECTOR_OPTIONS", "").split(",") if kv)}
-            self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict(), getattr(self, "_max_batch", None),
-                                             options=opts or None)
-            self._engine_version = self._version
-        return self._engine
+        with self._engine_lock:
+            if self._engine is None or self._engine_version != self._version:
+                version = self._version
+                # VTD_DETECTOR_OPTIONS="fuse_fpn_head=0,fuse_stem_pool=0": build options for A/B measurements (include/vtd.h)
+                opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_DETECTOR_OPTIONS", "").split(",") if kv)}
+                self._engine = _e.DetectorEngine(self.backbone_name, self.state_dict(), getattr(self, "_max_batch", None),
+                                                 options=opts or None)
+                self._engine_version = version
+            return self._engine
 
     def forward(self, x):
         return self.engine().forward(x, want_threshold=self.compute_threshold)
@@ -185,23 +192,25 @@ class CRNN(nn.Module):
         self._engine = None
         self._engine_version = -1
         self._version = 0
+        self._engine_lock = threading.Lock()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._version += 1
-        return out
+        try:
+            return super().load_state_dict(state_dict, strict=strict, **kw)
+        finally:   # torch copies the matching tensors before it raises on a mismatch: the packed copy is stale either way
+            self._version += 1
 
     def mark_dirty(self):
         self._version += 1
 
     def engine(self):
         from . import engine as _e
-        if self._engine is None or self._engine_version != self._version:
-            if self._engine is not None:
-                self._engine.close()
-            self._engine = _e.RecognizerEngine(self.vocab_size, self.state_dict(), getattr(self, "_max_crops", None))
-            self._engine_version = self._version
-        return self._engine
+        with self._engine_lock:   # see DBNet.engine
+            if self._engine is None or self._engine_version != self._version:
+                version = self._version
+                self._engine = _e.RecognizerEngine(self.vocab_size, self.state_dict(), getattr(self, "_max_crops", None))
+                self._engine_version = version
+            return self._engine
 
     def forward(self, x):
         return self.engine().forward_logits(x)

@@ -155,20 +155,41 @@ class VideoTextPipeline:
             staged = host.numpy()
             for i, f in enumerate(chunk):
                 staged[i] = f
-            job = self.submit_detection(DeviceFrames(host, stream=self._upload))
+            try:
+                job = self.submit_detection(DeviceFrames(host, stream=self._upload))
+            except Exception as e:
+                # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
+                # that cannot be enqueued degrades to empty detections for its frames, the video goes on
+                logger.error(f"Detection failed: {e}")
+                job = {"failed": True}
             job["info"], job["host"] = info, host
             self._inflight.append(job)
-            if len(self._inflight) >= 2 and "rec" not in self._inflight[-2]:
-                self.submit_recognition(self._inflight[-2])
+            if len(self._inflight) >= 2:
+                self._try_recognition(self._inflight[-2])
             if len(self._inflight) >= 3:
                 out += self._retire(self._inflight.pop(0))
         return out
 
+    def _try_recognition(self, job):
+        if "rec" in job or job.get("failed"):
+            return
+        try:
+            self.submit_recognition(job)
+        except Exception as e:
+            logger.error(f"Detection failed: {e}")
+            job["failed"] = True
+
     def _retire(self, job) -> List[Dict]:
         from .engine import PINNED
-        if "rec" not in job:
-            self.submit_recognition(job)
-        res = self.collect(job, job["info"])
+        self._try_recognition(job)
+        res = None
+        if not job.get("failed"):
+            try:
+                res = self.collect(job, job["info"])
+            except Exception as e:
+                logger.error(f"Batch collection failed: {e}")
+        if res is None:
+            res = [{"frame_number": num, "timestamp": ts, "detections": []} for num, ts in job["info"]]
         PINNED.release(job["host"])
         return res
 
@@ -241,12 +262,16 @@ class VideoTextPipeline:
         # already queued on the caller's stream, and its narrow kernels (LSTM recurrence: 17 workgroups, CTC decode, crop)
         # then fill CUs the detector's convolutions leave idle between launches instead of serialising behind them.
         stream = self._recognizer_stream()
-        if stream is None:
-            rec = self.recognizer.submit_boxes(job["batch"], boxes)
-        else:
-            stream.wait_event(job["det"]["event"])  # frames uploaded + detector done with them, in stream order
-            with torch.cuda.stream(stream):
+        try:
+            if stream is None:
                 rec = self.recognizer.submit_boxes(job["batch"], boxes)
+            else:
+                stream.wait_event(job["det"]["event"])  # frames uploaded + detector done with them, in stream order
+                with torch.cuda.stream(stream):
+                    rec = self.recognizer.submit_boxes(job["batch"], boxes)
+        except Exception as e:
+            logger.error(f"CRNN batch recognition failed: {e}")
+            rec, job["rec_failed"] = None, True
         job.update(detections=detections, owners=owners, rec=rec)
         return job
 
@@ -260,7 +285,13 @@ class VideoTextPipeline:
     def collect(self, job, frame_info=None) -> List[Dict]:
         n = job["batch"].n
         frame_info = frame_info or [(i, 0.0) for i in range(n)]
-        texts = self.recognizer.finish_boxes(job["rec"])
+        try:
+            if job.get("rec_failed"):
+                raise RuntimeError("recogniser submission failed")
+            texts = self.recognizer.finish_boxes(job["rec"])
+        except Exception as e:   # text_recognizer.py:138-140: log, empty text, zero confidence, detections kept
+            logger.error(f"CRNN batch recognition failed: {e}")
+            texts = [{"text": "", "confidence": 0.0}] * len(job["owners"])
         per_frame = [[] for _ in range(n)]
         for (i, j), rec in zip(job["owners"], texts):
             det = job["detections"][i][j]
