@@ -88,6 +88,17 @@ int vtd_detector_num_ops(const vtd_detector* d);
 int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name_cap, double* total_ms, int64_t* calls,
                              double* total_macs, vtd_stream stream);
 
+/* Kernel-selection table.  Which tile configuration / kernel variant runs a convolution is decided per launch slot and
+ * power-of-two batch bucket: from the table when it holds a valid entry, else by a timing contest on first use (whose result
+ * joins the table).  set_tuning merges a table (text lines "<signature>|n<bucket> <config id>", '#' comments) -- the one shipped
+ * with the package, or rank 0's, so that every process and every rank selects the same kernels and produces bit-identical
+ * maps; get_tuning serialises the current table into buf (NUL-terminated, truncated to capacity) and returns the size
+ * needed; tuning_measured tells whether any entry came from this process's own contest.  The reference has no counterpart
+ * (ATen picks its kernels internally). */
+int vtd_detector_set_tuning(vtd_detector* d, const char* table_text);
+int64_t vtd_detector_get_tuning(const vtd_detector* d, char* buf, int64_t capacity);
+int vtd_detector_tuning_measured(const vtd_detector* d);
+
 /* ---- post-process: TextDetector._post_process (text_detector.py:143-178) ------------------------ */
 /* Workspace for maps of map_h x map_w (the reference hard-codes 640 in the bbox arithmetic but its tests feed
  * 160x160 maps: any 2-D size works) and up to max_batch maps per call; max_out detections kept per frame. */
@@ -120,6 +131,10 @@ int vtd_recognizer_forward(vtd_recognizer* r, int ncrops, float* logits_dev, vtd
  * "h0", "h1" ([n,512,1,31] LSTM layer outputs).  Synchronises the stream. */
 int vtd_recognizer_read_tap(vtd_recognizer* r, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream);
 int64_t vtd_recognizer_macs_per_crop(const vtd_recognizer* r);
+/* Kernel-selection table of the recogniser (see vtd_detector_set_tuning); buckets are powers of two of the crop count. */
+int vtd_recognizer_set_tuning(vtd_recognizer* r, const char* table_text);
+int64_t vtd_recognizer_get_tuning(const vtd_recognizer* r, char* buf, int64_t capacity);
+int vtd_recognizer_tuning_measured(const vtd_recognizer* r);
 /* [softmax(dim=2) +] TextRecognizer._decode_prediction (text_recognizer.py:126,142-167) for n sequences of
  * dense [T,V] rows (T <= 128): apply_softmax=1 takes logits and fuses the softmax, 0 takes probabilities as
  * _decode_prediction itself does.  id2char_dev[V]: code point per class id or -1 for ids that emit nothing

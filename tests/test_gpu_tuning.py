@@ -1,0 +1,81 @@
+"""Deterministic kernel selection (include/vtd.h: vtd_*_set_tuning): with the shipped table two engines built in separate
+processes pick the same kernels and produce bit-identical probability maps / logits; a table entry really steers the
+launch; invalid entries are ignored."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vtd_amd import nets as mynets
+from vtd_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch
+from vtd_amd import nets as mynets, synth, weights
+from vtd_amd.engine import DetectorEngine, DeviceFrames, RecognizerEngine
+sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+eng = DetectorEngine("resnet18", sd, max_batch=4)
+frames = np.stack([synth.text_frame(60 + i)[0] for i in range(3)])
+prob = eng.forward(DeviceFrames(frames))["probability"].cpu().numpy()
+rec = RecognizerEngine(97, weights.calibrated_crnn_state_dict(11), max_crops=8)
+logits = rec.forward_logits(torch.from_numpy(synth.glyph_batch(21, 8))).cpu().numpy()
+print(json.dumps({"prob": hashlib.sha256(prob.tobytes()).hexdigest(), "logits": hashlib.sha256(logits.tobytes()).hexdigest(),
+                  "det_tuning": eng.tuning(), "rec_tuning": rec.tuning(),
+                  "measured": [eng.tuning_measured, rec.tuning_measured]}))
+"""
+
+
+def _child():
+    r = subprocess.run([sys.executable, "-c", _CHILD, os.path.join(ROOT, "video-text-detection-system_amd"), ROOT],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_processes_same_kernels_bit_identical_outputs(hip):
+    from vtd_amd.engine import shipped_tuning_text
+    assert shipped_tuning_text(), "the package ships a kernel-selection table (vtd_amd/tuning/gfx950.txt)"
+    a, b = _child(), _child()
+    assert a["det_tuning"] == b["det_tuning"] and a["rec_tuning"] == b["rec_tuning"]
+    assert a["prob"] == b["prob"] and a["logits"] == b["logits"]
+    # the shipped table covers these shapes: nothing was decided by a timing contest in either process
+    assert a["measured"] == [False, False] and b["measured"] == [False, False]
+
+
+def test_table_entries_steer_the_launch_and_invalid_ones_are_ignored(hip):
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(0))
+    eng = DetectorEngine("resnet18", sd, max_batch=2)
+    try:
+        ref = eng.forward(x)["probability"].cpu().numpy()
+        table = eng.tuning()
+        keys = [k for k in table if k.endswith("|n2")]
+        assert len(keys) >= 15
+        # move every implicit-GEMM slot of this bucket to another valid tile shape: outputs stay within the fp16 tolerance,
+        # the table reports the new ids, and the result changes bitwise somewhere (the entry was honoured)
+        forced = {k: (5 if table[k] != 5 else 6) for k in keys if table[k] < 8}
+        eng.set_tuning("".join(f"{k} {v}\n" for k, v in forced.items()) + "# a comment line\nconv|bogus|n2 3\n")
+        out = eng.forward(x)["probability"].cpu().numpy()
+        now = eng.tuning()
+        assert all(now[k] == v for k, v in forced.items())
+        assert float(np.abs(out - ref).max()) <= 2e-3
+        assert not np.array_equal(out, ref)
+        # an id that is not valid for the slot is ignored: the contest decides and overwrites it
+        bad_key = keys[0]
+        eng.set_tuning(f"{bad_key} 77\n")
+        eng.forward(x)
+        assert eng.tuning()[bad_key] != 77 and eng.tuning_measured
+        assert eng.lib.vtd_detector_set_tuning(eng.handle, b"no value here\n") != 0
+    finally:
+        eng.close()

@@ -191,3 +191,31 @@ def test_rank_aware_process_video_equals_single_process(tmp_path):
                 "avg_recognition_confidence"):
         assert r0["summary"][key] == single["summary"][key], key
     assert r0["_progress"] == r1["_progress"] and r0["_progress"][-1][0] in (16, N_VIDEO)
+
+
+# ---- kernel-selection tables travel from rank 0 to every rank -----------------------------------------------------------
+class _FakeEngine:
+    def __init__(self, text):
+        self.text = text
+
+    def tuning_text(self):
+        return self.text
+
+    def set_tuning(self, text):
+        self.text = text
+
+
+def _tuning_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    engines = [_FakeEngine(f"conv|a|n4 {3 + rank}\n"), _FakeEngine(f"conv|b|n8 {100 + rank}\n")]
+    shard.sync_tuning(engines)
+    json.dump([e.text for e in engines], open(os.path.join(out_dir, f"tuning_rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_tuning_table_reaches_every_rank(tmp_path):
+    mp.spawn(_tuning_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    t0 = json.load(open(tmp_path / "tuning_rank0.json"))
+    t1 = json.load(open(tmp_path / "tuning_rank1.json"))
+    assert t0 == t1 == ["conv|a|n4 3\n", "conv|b|n8 100\n"]

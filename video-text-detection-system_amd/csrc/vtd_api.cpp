@@ -240,12 +240,10 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
             if (const char* v = std::getenv("VTD_AUTOTUNE_VERBOSE"); v && v[0] == '1')
                 std::fprintf(stderr, "[autotune] head entry variant %d: %.1f us per launch incl. border tiles (best so far %.1f, cfg %d)\n", vcfg,
                              ms / 3.f * 1e3f, best / 3.f * 1e3f, best_id);
-            // The three implementations are within a few percent of one another in situ while this back-to-back timing
-            // flatters the gathered kernel (its inputs stay hot in the Infinity Cache between repetitions): the halo-plane
-            // kernels win anything up to 10 % (a third of the HBM reads and LDS-DMA traffic, which the other two streams of
-            // the pipeline compete for), the 16x16-block variant ahead of the 8x16 one.
-            const float ref = best_id == kHeadEntryHaloCfg ? best_gathered : best;
-            if (!rc && ms < ref * (variant ? 1.10f : 1.05f)) { best = ms; best_id = vcfg; }
+            // Plain timing, no hand-set handicaps: this back-to-back contest only serves shapes the shipped table
+            // (vtd_amd/tuning/gfx950.txt, chosen by in-situ measurement of the whole pipeline: tools/tune_table.py) lacks.
+            (void)best_gathered;
+            if (!rc && ms < best) { best = ms; best_id = vcfg; }
         }
     }
     int hbn = 0, htw = 0;
@@ -333,6 +331,12 @@ namespace vtd {
 struct ModelBase {
     StateDict sd;
     DeviceArena arena;
+    // Kernel-selection table: "<op signature>|n<batch bucket>" -> configuration id.  Filled from vtd_*_set_tuning (a table
+    // shipped with the package / broadcast by rank 0) and by the timing contest for shapes the table does not hold;
+    // vtd_*_get_tuning serialises it.  With a complete table kernel choice -- hence fp32 summation order -- is the same in
+    // every process and on every rank.
+    std::map<std::string, int> tuning;
+    bool tuning_measured = false;  // at least one entry came from this process's own timing contest
     int alloc_tensor(TensorDesc& t) {
         void* p = nullptr;
         int rc = arena.alloc(&p, (size_t)tensor_elems(t) * sizeof(half_t), true);
@@ -345,6 +349,84 @@ struct ModelBase {
         return &it->second;
     }
 };
+
+// Signature of one convolution launch slot: everything kernel choice may depend on except the batch.
+static std::string conv_signature(const ConvOp& c) {
+    char buf[192];
+    std::snprintf(buf, sizeof buf, "conv|in%dx%dx%d|out%dx%d|co%d|K%d|s%d|f%x|r%d|c%d", c.in.h, c.in.w, c.in.c, c.ho, c.wo, c.cout, c.K,
+                  c.stride, (unsigned)c.flags, c.has_res ? 1 + c.res_shift : 0, c.plist ? 1 : 0);
+    return buf;
+}
+
+static bool config_valid_for(const ConvOp& c, int n, int cfg) {
+    ConvParams p;
+    fill_conv_params(c, n, p);
+    if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) return p.plist && c.he_steps && c.tile_combo_border;
+    if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg) {
+        int bn = 0, tw = 0;
+        if (!vtd_conv_halo_supported(p, &bn, &tw)) return false;
+        return cfg != kHaloC64Cfg || vtd_conv_halo_c64_supported(p, tw);
+    }
+    return cfg >= 0 && cfg < vtd_conv_num_configs() && vtd_conv_config_valid(p, cfg);
+}
+
+// Configuration of one launch slot at batch bucket n: the table's entry when it has a valid one, else the timing contest
+// (whose result joins the table), else -1 (built-in heuristic).
+static int choose_config(ModelBase* m, const ConvOp& c, int n, hipStream_t s, int* cfg) {
+    const std::string key = conv_signature(c) + "|n" + std::to_string(n);
+    auto it = m->tuning.find(key);
+    if (it != m->tuning.end() && config_valid_for(c, n, it->second)) {
+        *cfg = it->second;
+        return 0;
+    }
+    *cfg = -1;
+    if (!autotune_enabled()) return 0;
+    int rc = autotune_conv(c, n, s, cfg);
+    if (!rc && *cfg >= 0) {
+        m->tuning[key] = *cfg;
+        m->tuning_measured = true;
+    }
+    return rc;
+}
+
+static int set_tuning_text(ModelBase* m, const char* text) {
+    if (!m || !text) return ERR_ARG;
+    const char* p = text;
+    while (*p) {
+        const char* eol = std::strchr(p, '\n');
+        std::string line = eol ? std::string(p, eol) : std::string(p);
+        p = eol ? eol + 1 : p + line.size();
+        if (line.empty() || line[0] == '#') continue;
+        const size_t sp = line.find_last_of(" \t");
+        if (sp == std::string::npos || sp + 1 >= line.size()) return ERR_ARG;
+        char* end = nullptr;
+        const long v = std::strtol(line.c_str() + sp + 1, &end, 10);
+        if (!end || *end != 0) return ERR_ARG;
+        size_t ke = sp;
+        while (ke > 0 && (line[ke - 1] == ' ' || line[ke - 1] == '\t')) --ke;
+        m->tuning[line.substr(0, ke)] = (int)v;
+    }
+    return 0;
+}
+
+static int64_t get_tuning_text(const ModelBase* m, char* buf, int64_t cap) {
+    if (!m) return ERR_ARG;
+    std::string out;
+    for (const auto& kv : m->tuning) out += kv.first + " " + std::to_string(kv.second) + "\n";
+    if (buf && cap > 0) {
+        const size_t ncopy = std::min((size_t)cap - 1, out.size());
+        std::memcpy(buf, out.data(), ncopy);
+        buf[ncopy] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
+
+static int batch_bucket(int n, int cap) {
+    int b = 1;
+    while (b < n) b <<= 1;
+    return std::min(b, cap);
+}
+
 }  // namespace vtd
 
 struct vtd_detector : vtd::ModelBase {
@@ -1156,16 +1238,17 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
     if (n <= 0 || n > d->max_batch) return ERR_BATCH;
     hipStream_t s = (hipStream_t)stream;
     float* outs[2] = {prob_dev, thresh_dev};
-    auto tit = d->tuned.find(n);
+    // kernel choice per power-of-two batch bucket (1, 2, 4, ... max_batch), decided at the bucket's own size
+    const int bucket = batch_bucket(n, d->max_batch);
+    auto tit = d->tuned.find(bucket);
     if (tit == d->tuned.end()) {
         std::vector<int> cfgs(d->ops.size(), -1);
-        if (autotune_enabled())
-            for (size_t oi = 0; oi < d->ops.size(); ++oi)
-                if (d->ops[oi].kind == Op::CONV) {
-                    int rc = autotune_conv(d->ops[oi].conv, n, s, &cfgs[oi]);
-                    if (rc) return rc;
-                }
-        tit = d->tuned.emplace(n, std::move(cfgs)).first;
+        for (size_t oi = 0; oi < d->ops.size(); ++oi)
+            if (d->ops[oi].kind == Op::CONV) {
+                int rc = choose_config(d, d->ops[oi].conv, bucket, s, &cfgs[oi]);
+                if (rc) return rc;
+            }
+        tit = d->tuned.emplace(bucket, std::move(cfgs)).first;
     }
     const std::vector<int>& cfgs = tit->second;
     for (size_t oi = 0; oi < d->ops.size(); ++oi) {
@@ -1215,6 +1298,17 @@ int vtd_detector_set_profiling(vtd_detector* d, int enable) {
 }
 
 int vtd_detector_num_ops(const vtd_detector* d) { return d ? (int)d->ops.size() : 0; }
+
+int vtd_detector_set_tuning(vtd_detector* d, const char* table_text) {
+    if (!d) return ERR_ARG;
+    int rc = set_tuning_text(d, table_text);
+    if (!rc) d->tuned.clear();  // decisions already taken are re-taken against the new table
+    return rc;
+}
+
+int64_t vtd_detector_get_tuning(const vtd_detector* d, char* buf, int64_t capacity) { return get_tuning_text(d, buf, capacity); }
+
+int vtd_detector_tuning_measured(const vtd_detector* d) { return d && d->tuning_measured ? 1 : 0; }
 
 int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name_cap, double* total_ms, int64_t* calls,
                              double* total_macs, vtd_stream stream) {
@@ -1447,20 +1541,16 @@ int vtd_recognizer_forward(vtd_recognizer* r, int ncrops, float* logits_dev, vtd
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // tile configs are tuned per power-of-two bucket of the crop count (the count changes from batch to batch)
-    int bucket = 1;
-    while (bucket < ncrops) bucket <<= 1;
-    bucket = std::min(bucket, r->max_crops);
+    const int bucket = batch_bucket(ncrops, r->max_crops);
     auto tit = r->tuned.find(bucket);
     const size_t nops = r->ops.size();
     if (tit == r->tuned.end()) {
         std::vector<int> cfgs(nops + 3, -1);
-        if (autotune_enabled()) {
-            for (size_t oi = 0; oi < nops; ++oi)
-                if (r->ops[oi].kind == Op::CONV && (rc = autotune_conv(r->ops[oi].conv, bucket, s, &cfgs[oi]))) return rc;
-            for (int layer = 0; layer < 2; ++layer)
-                if ((rc = autotune_conv(r->xs_gemm[layer], bucket, s, &cfgs[nops + layer]))) return rc;
-            if ((rc = autotune_conv(r->cls_gemm, bucket, s, &cfgs[nops + 2]))) return rc;
-        }
+        for (size_t oi = 0; oi < nops; ++oi)
+            if (r->ops[oi].kind == Op::CONV && (rc = choose_config(r, r->ops[oi].conv, bucket, s, &cfgs[oi]))) return rc;
+        for (int layer = 0; layer < 2; ++layer)
+            if ((rc = choose_config(r, r->xs_gemm[layer], bucket, s, &cfgs[nops + layer]))) return rc;
+        if ((rc = choose_config(r, r->cls_gemm, bucket, s, &cfgs[nops + 2]))) return rc;
         tit = r->tuned.emplace(bucket, std::move(cfgs)).first;
     }
     const std::vector<int>& cfgs = tit->second;
@@ -1501,6 +1591,17 @@ int vtd_recognizer_read_tap(vtd_recognizer* r, const char* name, int ncrops, flo
 }
 
 int64_t vtd_recognizer_macs_per_crop(const vtd_recognizer* r) { return r ? r->macs : 0; }
+
+int vtd_recognizer_set_tuning(vtd_recognizer* r, const char* table_text) {
+    if (!r) return ERR_ARG;
+    int rc = set_tuning_text(r, table_text);
+    if (!rc) r->tuned.clear();
+    return rc;
+}
+
+int64_t vtd_recognizer_get_tuning(const vtd_recognizer* r, char* buf, int64_t capacity) { return get_tuning_text(r, buf, capacity); }
+
+int vtd_recognizer_tuning_measured(const vtd_recognizer* r) { return r && r->tuning_measured ? 1 : 0; }
 
 int vtd_ctc_greedy_decode(const float* logits_dev, int n, int T, int V, const int32_t* id2char_dev, int blank_id, int apply_softmax,
                           int32_t* out_dev, vtd_stream stream) {

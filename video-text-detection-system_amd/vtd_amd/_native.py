@@ -43,6 +43,9 @@ SIGNATURES = {
     "vtd_detector_num_ops": (C.c_int, [C.c_void_p]),
     "vtd_detector_get_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_double), C.c_void_p]),
+    "vtd_detector_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vtd_detector_get_tuning": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "vtd_detector_tuning_measured": (C.c_int, [C.c_void_p]),
     "vtd_postproc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_postproc_destroy": (None, [C.c_void_p]),
     "vtd_postproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
@@ -56,6 +59,9 @@ SIGNATURES = {
     "vtd_recognizer_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vtd_recognizer_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vtd_recognizer_macs_per_crop": (C.c_int64, [C.c_void_p]),
+    "vtd_recognizer_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vtd_recognizer_get_tuning": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "vtd_recognizer_tuning_measured": (C.c_int, [C.c_void_p]),
     "vtd_ctc_greedy_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

@@ -13,6 +13,48 @@ from . import _native
 
 DEFAULT_MAX_BATCH = int(os.environ.get("VTD_MAX_BATCH", "32"))
 
+# Kernel-selection table shipped with the package (include/vtd.h: vtd_*_set_tuning): chosen on an MI355X by tools/tune_table.py,
+# loaded into every engine so that all processes / ranks run the same kernels.  VTD_TUNING_FILE points at another table,
+# VTD_TUNING=0 ignores tables (every shape is then decided by the in-process timing contest).
+TUNING_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950.txt")
+
+
+def shipped_tuning_text():
+    if os.environ.get("VTD_TUNING", "1") == "0":
+        return ""
+    path = os.environ.get("VTD_TUNING_FILE", TUNING_FILE)
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return ""
+
+
+class _Tunable:
+    """get / set of a handle's kernel-selection table (kind = 'detector' | 'recognizer')."""
+
+    _kind = None
+
+    def set_tuning(self, text):
+        if text:
+            fn = getattr(self.lib, f"vtd_{self._kind}_set_tuning")
+            _native.check(fn(self.handle, text.encode()), f"vtd_{self._kind}_set_tuning")
+
+    def tuning_text(self):
+        fn = getattr(self.lib, f"vtd_{self._kind}_get_tuning")
+        need = fn(self.handle, None, 0)
+        buf = C.create_string_buffer(int(need))
+        fn(self.handle, buf, need)
+        return buf.value.decode()
+
+    def tuning(self):
+        return {k: int(v) for k, v in (line.rsplit(" ", 1) for line in self.tuning_text().splitlines() if line)}
+
+    @property
+    def tuning_measured(self):
+        """True when some kernel choice of this engine came from its own timing contest (not from a table)."""
+        return bool(getattr(self.lib, f"vtd_{self._kind}_tuning_measured")(self.handle))
+
 
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -83,8 +125,10 @@ class DeviceFrames:
         return self.tensor.shape[2]
 
 
-class DetectorEngine:
+class DetectorEngine(_Tunable):
     """DBNet on the GPU: reference checkpoint tensors in, [n,1,640,640] probability maps out."""
+
+    _kind = "detector"
 
     def __init__(self, backbone, state_dict, max_batch=None, options=None):
         self.lib = _native.require()
@@ -104,6 +148,7 @@ class DetectorEngine:
                 _native.check(self.lib.vtd_detector_set_tensor(h, key.encode(), arr.ctypes.data, arr.size),
                               f"vtd_detector_set_tensor({key})")
             _native.check(self.lib.vtd_detector_finalize(h, _stream_ptr()), "vtd_detector_finalize")
+            self.set_tuning(shipped_tuning_text())
         except Exception:
             self.close()
             raise
@@ -247,8 +292,10 @@ def detector_profile(engine):
     return out
 
 
-class RecognizerEngine:
+class RecognizerEngine(_Tunable):
     """CRNN on the GPU: crops (or reference-format [n,3,32,128] tensors) in, [n,31,V] logits / decoded text out."""
+
+    _kind = "recognizer"
 
     T = 31
 
@@ -268,6 +315,7 @@ class RecognizerEngine:
                 _native.check(self.lib.vtd_recognizer_set_tensor(h, key.encode(), arr.ctypes.data, arr.size),
                               f"vtd_recognizer_set_tensor({key})")
             _native.check(self.lib.vtd_recognizer_finalize(h, _stream_ptr()), "vtd_recognizer_finalize")
+            self.set_tuning(shipped_tuning_text())
         except Exception:
             self.close()
             raise

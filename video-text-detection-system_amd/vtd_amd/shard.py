@@ -37,6 +37,19 @@ def comm_device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
+def sync_tuning(engines, group=None, src=0):
+    """Rank `src`'s kernel-selection tables (whatever its engines measured on top of the shipped table) become every
+    rank's: call it after rank `src` has run its priming pass and before the others run theirs, so all ranks launch the
+    same kernels and produce bit-identical maps.  `engines`: list of DetectorEngine / RecognizerEngine, same order on
+    every rank.  Returns the table texts."""
+    texts = [e.tuning_text() for e in engines] if dist.get_rank(group) == src else [None] * len(engines)
+    dist.broadcast_object_list(texts, src=src, group=group)
+    if dist.get_rank(group) != src:
+        for e, t in zip(engines, texts):
+            e.set_tuning(t)
+    return texts
+
+
 def gather_detections(records, counts, group=None):
     """records: [F, MAX_DET, 16] int32, counts: [F] int32 for this rank's F frames (same F on every rank, pad with
     count 0).  Returns ([W, F, MAX_DET, 16], [W, F]) on every rank."""
