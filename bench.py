@@ -162,7 +162,9 @@ def main():
     pipe = VideoTextPipeline(use_transformer_ocr=False, backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64
     pipe.detector.model.load_state_dict(sd)
-    rec_sd = weights.margin_crnn_state_dict(11)
+    # VTD_BENCH_CRNN=default: torch-default-init recogniser weights (round-1 bench; every crop decodes to two characters)
+    rec_sd = (mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11) if os.environ.get("VTD_BENCH_CRNN") == "default"
+              else weights.margin_crnn_state_dict(11))
     pipe.recognizer.model.load_state_dict(rec_sd)
     eng = pipe.detector.model.engine()
     lib = eng.lib

@@ -52,30 +52,37 @@ def test_two_processes_same_kernels_bit_identical_outputs(hip):
     assert a["measured"] == [False, False] and b["measured"] == [False, False]
 
 
-def test_table_entries_steer_the_launch_and_invalid_ones_are_ignored(hip):
+def test_table_entries_steer_the_launch_and_invalid_ones_are_ignored(hip, monkeypatch):
     from vtd_amd.engine import DetectorEngine
     sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
     x = torch.randn(2, 3, 640, 640, generator=torch.Generator().manual_seed(0))
+    monkeypatch.setenv("VTD_TUNING", "0")     # start from an empty table: every entry below is one of this engine's own slots
     eng = DetectorEngine("resnet18", sd, max_batch=2)
     try:
+        assert eng.tuning() == {}
         ref = eng.forward(x)["probability"].cpu().numpy()
         table = eng.tuning()
+        assert eng.tuning_measured
         keys = [k for k in table if k.endswith("|n2")]
-        assert len(keys) >= 15
-        # move every implicit-GEMM slot of this bucket to another valid tile shape: outputs stay within the fp16 tolerance,
-        # the table reports the new ids, and the result changes bitwise somewhere (the entry was honoured)
+        assert len(keys) >= 15 and len(keys) == len(table)
+        # move every implicit-GEMM slot of this bucket to another valid tile shape: the table reports the new ids, the launch
+        # descriptions name the forced tile (the entry was honoured), outputs stay within the fp16 tolerance (the tile shapes
+        # share one K walk, so they may even agree bit for bit)
+        from vtd_amd.engine import detector_profile
         forced = {k: (5 if table[k] != 5 else 6) for k in keys if table[k] < 8}
+        assert len(forced) >= 8
         eng.set_tuning("".join(f"{k} {v}\n" for k, v in forced.items()) + "# a comment line\nconv|bogus|n2 3\n")
         out = eng.forward(x)["probability"].cpu().numpy()
         now = eng.tuning()
         assert all(now[k] == v for k, v in forced.items())
+        names = [row[0] for row in detector_profile(eng)]
+        assert sum("conv_igemm<128,64,s2>" in nm or "conv_igemm<128,64,s3>" in nm for nm in names) >= len(forced)
         assert float(np.abs(out - ref).max()) <= 2e-3
-        assert not np.array_equal(out, ref)
         # an id that is not valid for the slot is ignored: the contest decides and overwrites it
         bad_key = keys[0]
         eng.set_tuning(f"{bad_key} 77\n")
         eng.forward(x)
-        assert eng.tuning()[bad_key] != 77 and eng.tuning_measured
+        assert eng.tuning()[bad_key] != 77
         assert eng.lib.vtd_detector_set_tuning(eng.handle, b"no value here\n") != 0
     finally:
         eng.close()
