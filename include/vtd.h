@@ -142,6 +142,53 @@ int vtd_recognizer_tuning_measured(const vtd_recognizer* r);
 int vtd_ctc_greedy_decode(const float* logits_dev, int n, int T, int V, const int32_t* id2char_dev, int blank_id, int apply_softmax,
                           int32_t* out_dev, vtd_stream stream);
 
+/* ---- Transformer recogniser: TrOCR (app/ml/models/text_recognizer.py:39-69) ----------------------------------------------
+ * TransformerRecognizer loads VisionEncoderDecoderModel "microsoft/trocr-base-printed" (ViT encoder + TrOCR decoder) and calls
+ * generate(pixel_values, max_length=50).  The architecture is a parameter (the checkpoint's config.json values; defaults of the
+ * Python binding restate trocr-base-printed), weights arrive by their transformers-4.36 state-dict keys. */
+typedef struct vtd_trocr vtd_trocr;
+typedef struct vtd_trocr_config {
+    int32_t image_size, patch_size;                       /* 384, 16 */
+    int32_t enc_hidden, enc_layers, enc_heads, enc_ffn;   /* 768, 12, 12, 3072; head width must be 64 */
+    int32_t enc_qkv_bias;                                 /* 0 for the TrOCR checkpoints */
+    float enc_ln_eps;                                     /* 1e-12 */
+    int32_t dec_hidden, dec_layers, dec_heads, dec_ffn;   /* 1024, 12, 16, 4096 */
+    int32_t vocab_size, max_positions;                    /* 50265, 512 */
+    float dec_ln_eps;                                     /* 1e-5 */
+    int32_t decoder_start_token_id, eos_token_id, pad_token_id; /* 2, 2, 1 */
+    int32_t max_length;                                   /* 50: text_recognizer.py:58 */
+} vtd_trocr_config;
+int vtd_trocr_create(const vtd_trocr_config* cfg, int max_crops, vtd_trocr** out);
+void vtd_trocr_destroy(vtd_trocr* t);
+/* One tensor of VisionEncoderDecoderModel.state_dict() (text_recognizer.py:42): "encoder.embeddings.*",
+ * "encoder.encoder.layer.N.*", "encoder.layernorm.*", "decoder.model.decoder.*", "decoder.output_projection.weight" (optional: tied to
+ * embed_tokens when absent); "encoder.pooler.*" is accepted and ignored.  float32, PyTorch memory order. */
+int vtd_trocr_set_tensor(vtd_trocr* t, const char* key, const float* host_data, int64_t numel);
+int vtd_trocr_finalize(vtd_trocr* t, vtd_stream stream);
+/* text_recognizer.py:48-55 for every box (frame, x1, y1, x2, y2) of frames_dev ([n_frames,H,W,3] uint8 BGR): crop, BGR->RGB,
+ * TrOCRProcessor (Pillow bilinear resize to image_size^2, /255, (x-0.5)/0.5), then the ViT encoder and the decoder's cross-attention
+ * keys / values.  boxes_host: [ncrops][5] int32 in HOST memory (the filter tables depend on the crop sizes). */
+int vtd_trocr_encode_crops(vtd_trocr* t, const uint8_t* frames_dev, int n_frames, int height, int width, const int32_t* boxes_host, int ncrops,
+                           vtd_stream stream);
+/* Alternative input: the pixel_values tensor the reference hands to generate(), [ncrops,3,S,S] float32 (text_recognizer.py:55). */
+int vtd_trocr_encode_pixels(vtd_trocr* t, const float* pixel_values_dev, int ncrops, vtd_stream stream);
+/* generate(pixel_values, max_length) (text_recognizer.py:58), greedy: ids_dev [ncrops][max_length] int32 receives
+ * decoder_start_token_id, the arg-max tokens up to and including <eos>, then pad_token_id.  logits_dev, if not NULL, receives the
+ * logits of every step as [ncrops][max_length-1][vtd_trocr_logits_stride()] float32.  forced_ids_dev ([ncrops][forced_len], optional):
+ * teacher forcing -- these tokens are fed instead of the arg-max (tensor-level tests).  Synchronises the stream now and then (to stop
+ * once every row has finished). */
+int vtd_trocr_generate(vtd_trocr* t, int ncrops, int max_length, const int32_t* forced_ids_dev, int forced_len, int32_t* ids_dev, float* logits_dev,
+                       vtd_stream stream);
+/* Test taps as float32 on the host: "pixel_values" [n,3,S,S], "encoder" (last_hidden_state) [n,tokens,enc_hidden]. */
+int vtd_trocr_read_tap(vtd_trocr* t, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream);
+int vtd_trocr_encoder_tokens(const vtd_trocr* t);
+int vtd_trocr_logits_stride(const vtd_trocr* t);
+int64_t vtd_trocr_macs_per_crop(const vtd_trocr* t);
+/* Kernel-selection table (see vtd_detector_set_tuning). */
+int vtd_trocr_set_tuning(vtd_trocr* t, const char* table_text);
+int64_t vtd_trocr_get_tuning(const vtd_trocr* t, char* buf, int64_t capacity);
+int vtd_trocr_tuning_measured(const vtd_trocr* t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,8 +201,7 @@ def test_text_recognizer_surface_and_mock_seam(hip):
     assert res["text"] == exp["text"] != "" and abs(res["confidence"] - exp["confidence"]) < 2e-3
     assert rec.recognize(None) == {"text": "", "confidence": 0.0}
     assert rec.recognize_batch([np.zeros((0, 5, 3), np.uint8)]) == [{"text": "", "confidence": 0.0}]
-    with pytest.raises(NotImplementedError):
-        TextRecognizer(use_transformer=True)
+    # use_transformer=True constructs too (tests/test_gpu_trocr.py drives it)
 
 
 @pytest.mark.parametrize("mode", ["1", "3"])

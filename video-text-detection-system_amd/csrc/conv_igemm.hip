@@ -379,6 +379,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
+            if (p.flags & EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            }
             if (p.flags & EPI_OUT_F16) {
                 half8 hv;
 #pragma unroll

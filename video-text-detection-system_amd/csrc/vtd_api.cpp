@@ -1610,3 +1610,5 @@ int vtd_ctc_greedy_decode(const float* logits_dev, int n, int T, int V, const in
 }
 
 }  // extern "C"
+
+#include "trocr_graph.inc"

@@ -33,6 +33,7 @@ enum : int {
     EPI_PIXEL_SHUFFLE = 4, // ConvTranspose2d(k=2,s=2) as GEMM: channel block q=(ky*2+kx) -> pixel (2oy+ky, 2ox+kx)
     EPI_OUT_F32 = 8,       // plain [M, ldc] float32 row-major output (LSTM gate pre-activations, logits)
     EPI_OUT_F16 = 32,      // plain [M, ldc] fp16 row-major output (LSTM gate pre-activations)
+    EPI_GELU = 64,         // exact (erf) GELU after the bias: the Transformer recogniser's MLPs
     EPI_HEAD_FINAL = 16,   // DB head tail fused: this GEMM is ConvT(64->64,k2,s2)+BN+ReLU; the epilogue applies
                            // ConvT(64->1,k2,s2)+sigmoid and writes the 4x4 fp32 probabilities of each input pixel
 };

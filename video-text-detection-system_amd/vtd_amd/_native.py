@@ -19,6 +19,15 @@ class NativeError(RuntimeError):
     pass
 
 
+class TrocrConfig(C.Structure):
+    """vtd_trocr_config of include/vtd.h"""
+    _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("enc_hidden", C.c_int32), ("enc_layers", C.c_int32),
+                ("enc_heads", C.c_int32), ("enc_ffn", C.c_int32), ("enc_qkv_bias", C.c_int32), ("enc_ln_eps", C.c_float),
+                ("dec_hidden", C.c_int32), ("dec_layers", C.c_int32), ("dec_heads", C.c_int32), ("dec_ffn", C.c_int32),
+                ("vocab_size", C.c_int32), ("max_positions", C.c_int32), ("dec_ln_eps", C.c_float),
+                ("decoder_start_token_id", C.c_int32), ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32), ("max_length", C.c_int32)]
+
+
 class Detection(C.Structure):
     _fields_ = [("bbox", C.c_int32 * 4), ("polygon", C.c_int32 * 8), ("confidence", C.c_float), ("area", C.c_float),
                 ("first_x", C.c_int32), ("first_y", C.c_int32)]
@@ -62,6 +71,20 @@ SIGNATURES = {
     "vtd_recognizer_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p]),
     "vtd_recognizer_get_tuning": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "vtd_recognizer_tuning_measured": (C.c_int, [C.c_void_p]),
+    "vtd_trocr_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vtd_trocr_destroy": (None, [C.c_void_p]),
+    "vtd_trocr_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "vtd_trocr_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtd_trocr_encode_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_trocr_encode_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_trocr_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vtd_trocr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vtd_trocr_encoder_tokens": (C.c_int, [C.c_void_p]),
+    "vtd_trocr_logits_stride": (C.c_int, [C.c_void_p]),
+    "vtd_trocr_macs_per_crop": (C.c_int64, [C.c_void_p]),
+    "vtd_trocr_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vtd_trocr_get_tuning": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "vtd_trocr_tuning_measured": (C.c_int, [C.c_void_p]),
     "vtd_ctc_greedy_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

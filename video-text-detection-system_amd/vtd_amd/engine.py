@@ -428,3 +428,126 @@ def decode_records_to_text(host):
     lens = host[:, 0].tolist()
     rows = host[:, 2:].tolist()
     return [("".join(map(chr, rows[i][:lens[i]])), conf[i]) for i in range(len(lens))]
+
+
+class TrOCREngine(_Tunable):
+    """The Transformer recogniser on the GPU (include/vtd.h: vtd_trocr_*): crops of resident frames, or the
+    ``pixel_values`` tensor the reference hands to ``generate``, in; greedy token ids out."""
+
+    _kind = "trocr"
+
+    def __init__(self, spec, state_dict, max_crops=None):
+        from .trocr_spec import hf4_key
+        self.lib = _native.require()
+        self.spec = spec
+        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "64"))
+        self.lock = threading.Lock()
+        cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
+                                  int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
+                                  spec.vocab_size, spec.max_positions, spec.dec_ln_eps, spec.decoder_start_token_id, spec.eos_token_id,
+                                  spec.pad_token_id, spec.max_length)
+        h = C.c_void_p()
+        _native.check(self.lib.vtd_trocr_create(C.byref(cfg), self.max_crops, C.byref(h)), "vtd_trocr_create")
+        self.handle = h
+        try:
+            for key, value in state_dict.items():
+                arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
+                _native.check(self.lib.vtd_trocr_set_tensor(h, hf4_key(key).encode(), arr.ctypes.data, arr.size), f"vtd_trocr_set_tensor({key})")
+            _native.check(self.lib.vtd_trocr_finalize(h, _stream_ptr()), "vtd_trocr_finalize")
+            self.set_tuning(shipped_tuning_text())
+        except Exception:
+            self.close()
+            raise
+        self.tokens = int(self.lib.vtd_trocr_encoder_tokens(h))
+        self.logits_stride = int(self.lib.vtd_trocr_logits_stride(h))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vtd_trocr_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def macs_per_crop(self):
+        return int(self.lib.vtd_trocr_macs_per_crop(self.handle))
+
+    def encode_pixels(self, pixel_values):
+        """[n,3,S,S] float (any device): ViT encoder + cross-attention keys / values.  Call with the lock held."""
+        s = self.spec.image_size
+        if not torch.is_tensor(pixel_values) or pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (3, s, s):
+            raise ValueError(f"pixel_values must be [n,3,{s},{s}] float")
+        x = pixel_values.to("cuda", torch.float32).contiguous()
+        _native.check(self.lib.vtd_trocr_encode_pixels(self.handle, C.c_void_p(x.data_ptr()), x.shape[0], _stream_ptr()), "vtd_trocr_encode_pixels")
+        self._keep = x
+        return x.shape[0]
+
+    def encode_crops(self, frames, boxes):
+        """boxes [(frame, x1, y1, x2, y2), ...] of a DeviceFrames batch.  Call with the lock held."""
+        b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
+        frames.wait_ready()
+        _native.check(self.lib.vtd_trocr_encode_crops(self.handle, C.c_void_p(frames.tensor.data_ptr()), frames.n, frames.height, frames.width,
+                                                      b.ctypes.data, b.shape[0], _stream_ptr()), "vtd_trocr_encode_crops")
+        self._keep = (b, frames)
+        return b.shape[0]
+
+    def generate_current(self, n, max_length=None, forced=None, want_logits=False):
+        """Greedy decode of the n crops encoded last.  Returns (ids [n,max_length] int32 cpu tensor, logits or None)."""
+        max_length = max_length or self.spec.max_length
+        ids = torch.empty((n, max_length), dtype=torch.int32, device="cuda")
+        logits = torch.zeros((n, max_length - 1, self.logits_stride), dtype=torch.float32, device="cuda") if want_logits else None
+        fdev, flen = None, 0
+        if forced is not None:
+            fdev = torch.as_tensor(np.asarray(forced), dtype=torch.int32).to("cuda").contiguous()
+            flen = fdev.shape[1]
+        _native.check(self.lib.vtd_trocr_generate(self.handle, n, max_length, C.c_void_p(fdev.data_ptr()) if fdev is not None else None, flen,
+                                                  C.c_void_p(ids.data_ptr()), C.c_void_p(logits.data_ptr()) if logits is not None else None,
+                                                  _stream_ptr()), "vtd_trocr_generate")
+        out = ids.cpu()
+        return out, (logits[..., :self.spec.vocab_size].cpu() if logits is not None else None)
+
+    def generate_pixels(self, pixel_values, **kw):
+        outs = []
+        with self.lock:
+            for i in range(0, pixel_values.shape[0], self.max_crops):
+                n = self.encode_pixels(pixel_values[i:i + self.max_crops])
+                outs.append(self.generate_current(n, **kw))
+        ids = torch.cat([o[0] for o in outs])
+        logits = torch.cat([o[1] for o in outs]) if outs[0][1] is not None else None
+        return ids, logits
+
+    def generate_crops(self, frames, boxes, **kw):
+        outs = []
+        with self.lock:
+            for i in range(0, len(boxes), self.max_crops):
+                n = self.encode_crops(frames, boxes[i:i + self.max_crops])
+                outs.append(self.generate_current(n, **kw)[0])
+        return torch.cat(outs)
+
+    def read_tap(self, name, n):
+        s = self.spec
+        shape = (n, 3, s.image_size, s.image_size) if name == "pixel_values" else (n, self.tokens, s.enc_hidden)
+        out = np.empty(shape, np.float32)
+        with self.lock:
+            _native.check(self.lib.vtd_trocr_read_tap(self.handle, name.encode(), n, out.ctypes.data, out.size, _stream_ptr()),
+                          f"vtd_trocr_read_tap({name})")
+        return out
+
+
+def trim_generated(ids, spec):
+    """Rows of generate()'s id matrix -> lists cut after <eos> (the start token, which is also id 2, stays)."""
+    out = []
+    for row in ids.tolist():
+        seq = [row[0]]
+        for tok in row[1:]:
+            seq.append(tok)
+            if tok == spec.eos_token_id:
+                break
+        while len(seq) > 1 and seq[-1] == spec.pad_token_id:
+            seq.pop()
+        out.append(seq)
+    return out

@@ -216,7 +216,7 @@ class VideoTextPipeline:
             return False
         if _is_overridden(self.detector, "detect", TextDetector) or _is_overridden(self.recognizer, "recognize", TextRecognizer):
             return False
-        if getattr(self.recognizer, "use_transformer", True) or not frames:
+        if not frames:
             return False
         shape = getattr(frames[0], "shape", None)
         return (shape is not None and len(shape) == 3 and shape[2] == 3

@@ -3,10 +3,13 @@ engine: ``recognize`` / ``recognize_batch`` return ``{'text','confidence'}`` dic
 ``CRNN`` whose ``forward`` is honoured when patched (tests/test_models.py:73,88,190 of the reference return
 ``[B,10,V]`` tensors from it); ``.vocab`` is the 97-entry table.
 
-The Transformer (TrOCR) recogniser (text_recognizer.py:39-69) is SURVEY section 8(f) rank 1 -- not built this
-round: ``use_transformer=True`` raises instead of silently falling back (weights/tokenizer cannot be fetched).
+The Transformer (TrOCR) recogniser (text_recognizer.py:39-69) runs on the same library (csrc/trocr.hip): ViT encoder,
+autoregressive decoder with KV cache, greedy ``generate(max_length=50)``; confidence is the reference's hard-coded 0.95.
 """
+import json
 import logging
+import os
+import threading
 
 import numpy as np
 import torch
@@ -19,9 +22,107 @@ from .vocab import build_vocab, id_to_char_table
 logger = logging.getLogger(__name__)
 
 
+def _bytes_to_unicode():
+    """GPT-2 / RoBERTa byte-level BPE alphabet: printable stand-ins for the 256 byte values."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, map(chr, cs)))
+
+
 class TransformerRecognizer:
-    def __init__(self, model_name: str = "microsoft/trocr-base-printed"):
-        raise NotImplementedError("TrOCR recogniser: next-row scope (SURVEY 8f); no weights can be fetched offline")
+    """``TransformerRecognizer`` of the reference (text_recognizer.py:39-69).
+
+    ``model_name``: the reference downloads ``microsoft/trocr-base-printed`` from the hub.  Nothing can be fetched here, so: a
+    local directory holding the checkpoint (``model.safetensors`` or ``pytorch_model.bin`` = the state dict of
+    ``VisionEncoderDecoderModel``, optionally ``vocab.json`` for the byte-level BPE decode) is loaded; any other name yields the
+    trocr-base-printed architecture on deterministic seeded weights (logged) -- the same repair the detector applies to
+    ``pretrained=True``.  Without ``vocab.json`` token ids are rendered as ``<id>`` markers (tokenizer parity is unpinned)."""
+
+    SPECIAL = (0, 1, 2, 3)  # <s>, <pad>, </s>, <unk>: dropped by batch_decode(skip_special_tokens=True)
+
+    def __init__(self, model_name: str = "microsoft/trocr-base-printed", spec=None, max_crops: int = None):
+        from .trocr_spec import BASE_PRINTED
+        _native.require()
+        self.spec = spec or BASE_PRINTED
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.model_name = model_name
+        self._max_crops = max_crops
+        self._sd = None
+        self._engine = None
+        self._lock = threading.Lock()
+        self._id2tok = None
+        self._byte_decoder = {v: k for k, v in _bytes_to_unicode().items()}
+        if model_name and os.path.isdir(model_name):
+            self._load_directory(model_name)
+        else:
+            logger.warning(f"TrOCR checkpoint {model_name!r} is not a local directory and cannot be fetched: "
+                           "running the trocr-base-printed architecture on seeded weights")
+
+    def _load_directory(self, path):
+        st, pt = os.path.join(path, "model.safetensors"), os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            self._sd = load_file(st)
+        elif os.path.exists(pt):
+            self._sd = torch.load(pt, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {path}")
+        vocab = os.path.join(path, "vocab.json")
+        if os.path.exists(vocab):
+            self._id2tok = {int(i): tok for tok, i in json.load(open(vocab, encoding="utf-8")).items()}
+
+    def load_state_dict(self, state_dict):
+        with self._lock:
+            self._sd = dict(state_dict)
+            self._engine = None
+
+    def engine(self):
+        from . import weights
+        from .engine import TrOCREngine
+        with self._lock:
+            if self._engine is None:
+                sd = self._sd if self._sd is not None else weights.trocr_state_dict(self.spec, seed=0)
+                self._engine = TrOCREngine(self.spec, sd, self._max_crops)
+                self._sd = None  # the engine holds the packed copy
+            return self._engine
+
+    def decode_ids(self, ids):
+        """batch_decode(skip_special_tokens=True) of one id sequence."""
+        body = [i for i in ids if i not in self.SPECIAL]
+        if self._id2tok is None:
+            return "".join(f"<{i}>" for i in body)
+        text = "".join(self._id2tok.get(i, "") for i in body)
+        return bytearray(self._byte_decoder.get(ch, 32) for ch in text).decode("utf-8", errors="replace")
+
+    def recognize_ids(self, images):
+        """Greedy token ids per image, as generate() returns them per call (start token ... </s>)."""
+        from .engine import trim_generated
+        eng = self.engine()
+        out = []
+        for img in images:
+            img = np.ascontiguousarray(img)
+            if img.ndim != 3 or img.shape[2] != 3 or img.size == 0:
+                raise ValueError("expected an HxWx3 BGR crop")
+            ids = eng.generate_crops(DeviceFrames(img), [(0, 0, 0, img.shape[1], img.shape[0])])
+            out.append(trim_generated(ids, self.spec)[0])
+        return out
+
+    def recognize_boxes_ids(self, frames: DeviceFrames, boxes):
+        from .engine import trim_generated
+        return trim_generated(self.engine().generate_crops(frames, boxes), self.spec)
+
+    def recognize(self, image):
+        try:
+            return {"text": self.decode_ids(self.recognize_ids([image])[0]), "confidence": 0.95}
+        except Exception as e:
+            logger.error(f"Text recognition failed: {e}")
+            return {"text": "", "confidence": 0.0}
 
 
 class TextRecognizer:
@@ -32,7 +133,7 @@ class TextRecognizer:
         self.vocab = self._build_vocab()
         self._id2char = id_to_char_table(self.vocab)
         if use_transformer:
-            self.model = TransformerRecognizer()
+            self.model = TransformerRecognizer(model_path or "microsoft/trocr-base-printed", max_crops=max_crops)
         else:
             state = torch.random.get_rng_state()
             try:
@@ -105,6 +206,9 @@ class TextRecognizer:
     def submit_boxes(self, frames: DeviceFrames, boxes):
         if len(boxes) == 0:
             return None
+        if self.use_transformer:  # generate() synchronises between steps anyway: the ticket already holds the strings
+            ids = self.model.recognize_boxes_ids(frames, [tuple(int(v) for v in b) for b in boxes])
+            return {"transformer": [{"text": self.model.decode_ids(s), "confidence": 0.95} for s in ids]}
         eng = self.model.engine()
         if getattr(self, "_id2char_dev", None) is None:
             self._id2char_dev = torch.tensor(self._id2char, dtype=torch.int32, device="cuda")
@@ -114,6 +218,8 @@ class TextRecognizer:
     def finish_boxes(self, tickets):
         if not tickets:
             return []
+        if isinstance(tickets, dict) and "transformer" in tickets:
+            return tickets["transformer"]
         eng = self.model.engine()
         out = []
         for t in tickets:
@@ -124,6 +230,8 @@ class TextRecognizer:
     def recognize_boxes(self, frames: DeviceFrames, boxes):
         if len(boxes) == 0:
             return []
+        if self.use_transformer:
+            return self.finish_boxes(self.submit_boxes(frames, boxes))
         eng = self.model.engine()
         out = []
         for i in range(0, len(boxes), eng.max_crops):

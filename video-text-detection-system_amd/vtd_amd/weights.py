@@ -305,3 +305,72 @@ def margin_crnn_state_dict(seed=0, vocab_size=97, cls_gain=3.0):
             cw[k, col] = cls_gain * s * (1.0 if (code >> b) & 1 else -1.0)
     cb[dead] = -10.0 * cls_gain
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# TrOCR fixture weights (vtd_amd/trocr_spec.py).  No checkpoint can be fetched, so the architecture runs on seeded
+# random tensors in the reference pin's (transformers 4.36) key layout.  Plain N(0, 0.02) init makes greedy decoding
+# degenerate (the GELU MLPs' input-independent mean swamps the token signal: one token repeated 49 times whatever the
+# image), so the scales are chosen for a model that *reads its input*: unit-scale token embeddings and 0.3-scale position
+# embeddings carry the state, sublayers perturb it (std 0.01), cross-attention output is amplified (x2) so the image
+# decides without drowning the previous token, the output projection is untied and its <eos> row is scaled so sequences end after ~10 tokens.
+def trocr_state_dict(spec=None, seed=0, w_std=0.01, tok_std=1.0, pos_std=0.3, out_std=0.03, cross_gain=2.0, eos_gain=3.4, cross_sharp=1.0):
+    from .trocr_spec import BASE_PRINTED
+    s = spec or BASE_PRINTED
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    def ln(prefix, c, sd):
+        sd[prefix + ".weight"] = 1.0 + 0.1 * rn(c)
+        sd[prefix + ".bias"] = 0.02 * rn(c)
+
+    sd = OrderedDict()
+    C, F = s.enc_hidden, s.enc_ffn
+    sd["encoder.embeddings.cls_token"] = rn(1, 1, C, std=pos_std)
+    sd["encoder.embeddings.position_embeddings"] = rn(1, s.enc_tokens, C, std=pos_std)
+    sd["encoder.embeddings.patch_embeddings.projection.weight"] = rn(C, 3, s.patch_size, s.patch_size, std=0.03)
+    sd["encoder.embeddings.patch_embeddings.projection.bias"] = rn(C, std=0.02)
+    for i in range(s.enc_layers):
+        p = f"encoder.encoder.layer.{i}."
+        for name in ("query", "key", "value"):
+            sd[p + f"attention.attention.{name}.weight"] = rn(C, C, std=0.03)
+            if s.enc_qkv_bias:
+                sd[p + f"attention.attention.{name}.bias"] = rn(C, std=0.02)
+        sd[p + "attention.output.dense.weight"] = rn(C, C, std=0.03)
+        sd[p + "attention.output.dense.bias"] = rn(C, std=0.02)
+        sd[p + "intermediate.dense.weight"] = rn(F, C, std=0.03)
+        sd[p + "intermediate.dense.bias"] = rn(F, std=0.02)
+        sd[p + "output.dense.weight"] = rn(C, F, std=0.03)
+        sd[p + "output.dense.bias"] = rn(C, std=0.02)
+        ln(p + "layernorm_before", C, sd)
+        ln(p + "layernorm_after", C, sd)
+    ln("encoder.layernorm", C, sd)
+    D, DF = s.dec_hidden, s.dec_ffn
+    q = "decoder.model.decoder."
+    sd[q + "embed_tokens.weight"] = rn(s.vocab_size, D, std=tok_std)
+    sd[q + "embed_positions.weight"] = rn(s.max_positions + 2, D, std=pos_std)
+    ln(q + "layernorm_embedding", D, sd)
+    for i in range(s.dec_layers):
+        p = q + f"layers.{i}."
+        for att, kdim in (("self_attn", D), ("encoder_attn", C)):
+            for name in ("k_proj", "v_proj"):
+                # cross_sharp > 1: larger cross-attention key weights = a peaked (input-dependent) attention pattern
+                sd[p + f"{att}.{name}.weight"] = rn(D, kdim, std=w_std * (cross_sharp if (att, name) == ("encoder_attn", "k_proj") else 1.0))
+                sd[p + f"{att}.{name}.bias"] = rn(D, std=0.02)
+            sd[p + f"{att}.q_proj.weight"] = rn(D, D, std=w_std * 3.0)
+            sd[p + f"{att}.q_proj.bias"] = rn(D, std=0.02)
+            sd[p + f"{att}.out_proj.weight"] = rn(D, D, std=w_std * (cross_gain if att == "encoder_attn" else 1.0))
+            sd[p + f"{att}.out_proj.bias"] = rn(D, std=0.02)
+        ln(p + "self_attn_layer_norm", D, sd)
+        ln(p + "encoder_attn_layer_norm", D, sd)
+        sd[p + "fc1.weight"] = rn(DF, D, std=w_std)
+        sd[p + "fc1.bias"] = rn(DF, std=0.02)
+        sd[p + "fc2.weight"] = rn(D, DF, std=w_std)
+        sd[p + "fc2.bias"] = rn(D, std=0.02)
+        ln(p + "final_layer_norm", D, sd)
+    out = rn(s.vocab_size, D, std=out_std)
+    out[s.eos_token_id] *= eos_gain
+    sd["decoder.output_projection.weight"] = out
+    return sd
