@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--backbone", default="resnet18")
     ap.add_argument("--workload", default="full", choices=["full", "detector"],
                     help="full = BASELINE configs[2] (detect + recognize); detector = configs[1]")
+    ap.add_argument("--recognizer", default="crnn", choices=["crnn", "trocr"],
+                    help="crnn = BASELINE configs[2]; trocr = the Transformer recogniser of configs[4] (trocr-base-printed architecture, seeded weights)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4] batch: half of the frames 720p, half 1080p (two equally sized sub-batches per step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
     ap.add_argument("--upload", action="store_true",
@@ -149,7 +153,15 @@ def main():
         dist.init_process_group(os.environ.get("VTD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     B, H, W = args.batch, args.height, args.width
-    frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
+    if args.mixed:   # configs[4]: alternating 720p / 1080p frames, processed as one 720p and one 1080p sub-batch per step
+        if args.upload or args.workload != "full" or B % 2:
+            raise SystemExit("--mixed needs --workload full, an even --batch and no --upload")
+        sizes = [(720, 1280), (1080, 1920)]
+        sub = [np.stack([synth.text_frame(2000 + rank * B + 2 * i + k, *sizes[k])[0] for i in range(B // 2)]) for k in range(2)]
+        sub_frames = [DeviceFrames(f) for f in sub]
+        frames = sub[0]
+    else:
+        frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
     dev_frames = DeviceFrames(frames)
     if args.upload:
         host_frames = torch.from_numpy(frames).pin_memory()
@@ -159,20 +171,28 @@ def main():
     from vtd_amd import shard
     from vtd_amd.pipeline import VideoTextPipeline
     os.environ["VTD_MAX_BATCH"] = str(B)
-    pipe = VideoTextPipeline(use_transformer_ocr=False, backbone=args.backbone, batch_size=B)
+    if args.recognizer == "trocr":
+        os.environ.setdefault("VTD_TROCR_MAX_CROPS", "512")
+    pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64
     pipe.detector.model.load_state_dict(sd)
     # VTD_BENCH_CRNN=default: torch-default-init recogniser weights (round-1 bench; every crop decodes to two characters)
     rec_sd = (mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11) if os.environ.get("VTD_BENCH_CRNN") == "default"
               else weights.margin_crnn_state_dict(11))
-    pipe.recognizer.model.load_state_dict(rec_sd)
+    if args.recognizer == "crnn":
+        pipe.recognizer.model.load_state_dict(rec_sd)
     eng = pipe.detector.model.engine()
     lib = eng.lib
     last = {}
 
     inflight = {"det": None, "rec": None}
 
+    turn = {"k": 0}
+
     def next_batch():
+        if args.mixed:
+            turn["k"] ^= 1
+            return sub_frames[turn["k"] ^ 1]
         return DeviceFrames(host_frames, stream=upload_stream) if args.upload else dev_frames
 
     def step_detector():
@@ -213,6 +233,8 @@ def main():
                 inflight["det"] = None
 
     def step():
+        if args.mixed:
+            step_full()
         rec, cnt = step_full() if args.workload == "full" else step_detector()
         if world > 1:
             # the one exchange step of the path: detection records of every rank to every rank.  Enqueued on the stream
@@ -293,7 +315,7 @@ def main():
                 return max(hits, key=lambda h: h["launches"]) if hits else None
 
             # launch-slot description (vtd_api.cpp) -> device kernel symbol of exactly that variant
-            symbol = next((sym for key, sym in (("head_entry_halo256", "head_entry_halo256_kernel("),
+            symbol = next((sym for key, sym in (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_halo256", "head_entry_halo256_kernel("),
                                                 ("head_entry_halo ", "head_entry_halo_kernel<"),
                                                 ("classed", "true>(")) if key in name), None)
             parts = [v for v in [pick(symbol) if symbol else None] if v]
@@ -366,7 +388,9 @@ def main():
             "data": "synthetic" + (" (uploaded from pinned host memory every step: PCIe-inclusive variant)" if args.upload else ""),
             "config": {"workload": (f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), fp16"
                                     if args.workload == "detector" else
-                                    f"B={B} {H}p frames, full pipeline: DBNet-{args.backbone} + crop + CRNN + CTC decode -> result dicts, fp16"),
+                                    f"B={B} {'mixed 720p/1080p' if args.mixed else str(H) + 'p'} frames, full pipeline: DBNet-{args.backbone} + crop + "
+                                    + ("TrOCR (ViT-base-384 encoder + 12-layer decoder, greedy max_length=50)" if args.recognizer == "trocr"
+                                       else "CRNN + CTC decode") + " -> result dicts, fp16"),
                        "global_batch": world * B, "frame": [H, W], "backbone": args.backbone,
                        "parallelism": f"frames sharded over {world} rank(s), detections all-gathered",
                        "detections_last_step_rank0": n_det,

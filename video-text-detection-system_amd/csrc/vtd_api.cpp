@@ -27,6 +27,8 @@ void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
 int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream);
+int vtd_head_entry_pair_tables(int py, int px, int c2ch, int* half_steps, int* plan);
+int vtd_launch_head_entry_pair(const ConvParams& c, const int* half_steps_dev, const int* plan_dev, int nh, hipStream_t stream);
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
 bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
@@ -109,6 +111,9 @@ struct ConvOp {
     int tiles_border = 0;
     const int* he_steps = nullptr;  // step tables of the four interior classes
     int he_nsteps = 0;
+    const int* hp_half_steps = nullptr;  // head_entry_pair.hip: half-step tables and halo prefetch plans of the four interior classes
+    const int* hp_plan = nullptr;
+    int hp_nh = 0;
     const int* tile_combo_b = nullptr;
     int tiles_per_img_b = 0;
     int tiles_per_img = 0, seg1_steps = 0, cin_steps2 = 0, kw2 = 0, s_step2 = 0, r_step2 = 0, img_h = 0, img_w = 0;
@@ -157,6 +162,7 @@ static const int kHaloCfg = 100;
 static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 64 -> 64 channels
 static const int kHalo64Cfg = 104;  // second-generation halo kernel: 64 output channels per workgroup, hand-pipelined
 static const int kHeadEntryHalo256Cfg = 103;  // same, 16x16 pixel blocks with 64x64 register tiles (hand-pipelined)
+static const int kHeadEntryPairCfg = 105;  // two 16x16 blocks per workgroup on one weight ring, 32-channel halos prefetched two groups ahead
 static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
@@ -167,6 +173,10 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
+    if (cfg == kHeadEntryPairCfg) {
+        if (!c.hp_half_steps || !c.tile_combo_border) return ERR_GEOMETRY;
+        return vtd_launch_head_entry_pair(p, c.hp_half_steps, c.hp_plan, c.hp_nh, s);
+    }
     if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) {  // interior classes only; border tiles = the next graph slot
         if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, cfg == kHeadEntryHalo256Cfg ? 1 : 0, s);
@@ -203,7 +213,8 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     int best_id = -1, rc = 0;
     if (p.plist) {  // tests: pin the composed conv to one tile configuration (8..11)
         const char* fc = std::getenv("VTD_FORCE_CLASSED_CFG");
-        if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || ((std::atoi(fc) == kHeadEntryHaloCfg || std::atoi(fc) == kHeadEntryHalo256Cfg) && c.he_steps))) {
+        if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || ((std::atoi(fc) == kHeadEntryHaloCfg || std::atoi(fc) == kHeadEntryHalo256Cfg) && c.he_steps) ||
+                   (std::atoi(fc) == kHeadEntryPairCfg && c.hp_half_steps))) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             *best_cfg = std::atoi(fc);
@@ -223,8 +234,9 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     }
     if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernels + border tiles
         const float best_gathered = best;
-        for (int variant = 0; variant < 2 && !rc; ++variant) {
-            const int vcfg = variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
+        for (int variant = 0; variant < 3 && !rc; ++variant) {
+            if (variant == 2 && !c.hp_half_steps) continue;
+            const int vcfg = variant == 2 ? kHeadEntryPairCfg : variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
             auto both = [&]() { int r = launch_conv_op(c, n, s, vcfg); return r ? r : launch_border_tiles(c, n, s); };
             if ((rc = both())) break;
             float ms = 1e30f;
@@ -361,6 +373,7 @@ static std::string conv_signature(const ConvOp& c) {
 static bool config_valid_for(const ConvOp& c, int n, int cfg) {
     ConvParams p;
     fill_conv_params(c, n, p);
+    if (cfg == kHeadEntryPairCfg) return p.plist && c.hp_half_steps && c.tile_combo_border;
     if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) return p.plist && c.he_steps && c.tile_combo_border;
     if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg) {
         int bn = 0, tw = 0;
@@ -375,7 +388,9 @@ static bool config_valid_for(const ConvOp& c, int n, int cfg) {
 static int choose_config(ModelBase* m, const ConvOp& c, int n, hipStream_t s, int* cfg) {
     const std::string key = conv_signature(c) + "|n" + std::to_string(n);
     auto it = m->tuning.find(key);
-    if (it != m->tuning.end() && config_valid_for(c, n, it->second)) {
+    // test switches that pin a kernel variant (VTD_FORCE_CLASSED_CFG, VTD_FORCE_HALO) are honoured by the contest: they outrank the table
+    const bool forced = std::getenv("VTD_FORCE_CLASSED_CFG") || std::getenv("VTD_FORCE_HALO");
+    if (!forced && it != m->tuning.end() && config_valid_for(c, n, it->second)) {
         *cfg = it->second;
         return 0;
     }
@@ -831,6 +846,21 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
         if ((rc = upload(d->arena, border.data(), border.size() * sizeof(int), &bd))) return rc;
         op.he_steps = (const int*)st; op.he_nsteps = nsteps;
         op.tile_combo_border = (const int*)bd; op.tiles_border = (int)border.size();
+        {   // pair kernel (head_entry_pair.hip): half-step tables + halo prefetch plans; only where its LDS budget holds (C2 of 64 channels)
+            const int nh = 25 * (c2.c / 32) + 72;
+            if (c2.c == 64) {
+                std::vector<int> hs((size_t)4 * nh * 2), plan((size_t)4 * nh);
+                bool ok = true;
+                for (int q = 0; q < 4 && ok; ++q)
+                    ok = vtd_head_entry_pair_tables(q >> 1, q & 1, c2.c, &hs[(size_t)q * nh * 2], &plan[(size_t)q * nh]) == nh;
+                if (ok) {
+                    void *hsd = nullptr, *pld = nullptr;
+                    if ((rc = upload(d->arena, hs.data(), hs.size() * sizeof(int), &hsd))) return rc;
+                    if ((rc = upload(d->arena, plan.data(), plan.size() * sizeof(int), &pld))) return rc;
+                    op.hp_half_steps = (const int*)hsd; op.hp_plan = (const int*)pld; op.hp_nh = nh;
+                }
+            }
+        }
     }
     op.bias = (float*)bt;  // first class doubles as the (unused) flat bias
     op.bias_tab = (const float*)bt;
@@ -1255,7 +1285,8 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
         const Op& o = d->ops[oi];
         int rc = 0;
         if (o.final_slot == 1 && !thresh_dev) continue;
-        if (o.kind == Op::BORDER && (oi == 0 || (cfgs[oi - 1] != kHeadEntryHaloCfg && cfgs[oi - 1] != kHeadEntryHalo256Cfg))) continue;  // the gathered kernel did every class
+        if (o.kind == Op::BORDER && (oi == 0 || (cfgs[oi - 1] != kHeadEntryHaloCfg && cfgs[oi - 1] != kHeadEntryHalo256Cfg && cfgs[oi - 1] != kHeadEntryPairCfg)))
+            continue;  // the gathered kernel did every class
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool prof = d->profiling && (d->prof_only < 0 || d->prof_only == (int)oi);
         if (prof) {
@@ -1334,7 +1365,10 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
                                       "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
-        if (cfg == kHeadEntryHalo256Cfg)
+        if (cfg == kHeadEntryPairCfg)
+            std::snprintf(name, name_cap, "head_entry_pair M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
+                          "next slot)", c.ho * c.wo, c.cout, c.K);
+        else if (cfg == kHeadEntryHalo256Cfg)
             std::snprintf(name, name_cap, "head_entry_halo256 M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
                           "next slot)", c.ho * c.wo, c.cout, c.K);
         else if (cfg == kHeadEntryHaloCfg)
