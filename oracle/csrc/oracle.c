@@ -30,7 +30,11 @@
 #include <string.h>
 #include <float.h>
 
-/* ------------------------------------------------------------------ Pillow resample */
+/* ------------------------------------------------------------------ Pillow resample
+ * Restates the 8-bit path of Pillow's src/libImaging/Resample.c (precompute_coeffs / normalize_coeffs_8bpc /
+ * ImagingResampleHorizontal_8bpc / ...Vertical_8bpc; Pillow is HPND-licensed, (c) Secret Labs AB / Fredrik Lundh / Alex Clark
+ * and contributors): same coefficient formula, same 22-bit fixed point, same rounding, so that it can be pinned bit-exact
+ * against the PIL installed here (tests/test_oracle_stages.py, tests/test_oracle_trocr.py). */
 
 #define PIL_PRECISION_BITS (32 - 8 - 2)
 
@@ -366,7 +370,18 @@ static void min_area_rect(const fpt *points, int n, float out[6]) {
 
 #define ORC_PI 3.1415926535897932384626433832795
 
-/* minAreaRect + boxPoints + np.int0 on an int contour; box[8] = 4 x (x,y) */
+/* minAreaRect + boxPoints + np.int0 on an int contour; box[8] = 4 x (x,y).
+ *
+ * Why an axis-aligned component whose contour spans x = 0..159 comes out as [0,158] and not [0,159] (tests/test_gpu_e2e_detector.py
+ * feeds the reference's own 160x160 all-foreground map): nothing here is exact.  rotatingCalipers normalises every hull edge with
+ * a float32 reciprocal length: for the edge (159, 0) that is inv_len = float32(1/159) = 0.0062893084 and the unit vector's x becomes
+ * 159 * inv_len = 0.99999994 (one ulp below 1).  The rectangle's width is the projection of the opposite corner on that vector,
+ * 159 * 0.99999994 = 158.99998 in float32, its centre 79.49999, and RotatedRect::points() rebuilds the far corner as
+ * centre + 0.5 * width = 158.99998.  np.int0 truncates toward zero -> 158.  The near corner is rebuilt as 0.0 (or -4.9e-15) -> 0.
+ * OpenCV 4.8.1's C++ performs the same float32 operations in the same order (modules/imgproc/src/rotcalipers.cpp,
+ * types.cpp RotatedRect::points), so the same one-pixel shrink is expected from it, but with cv2 not importable here that stays
+ * PARITY UNPINNED: the HIP post-process is bit-exact against THIS restatement (csrc/postprocess.hip replays it with
+ * -ffp-contract=off), not against a run of OpenCV. */
 static void min_area_box(const ipt *contour, int npts, int box[8]) {
     ipt *hull = (ipt *)malloc(sizeof(ipt) * (npts + 1));
     int n = convex_hull(contour, npts, hull);
