@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void head_entry_halo_kernel(const HeadHalo
     // output channels a K-step is only 0.13 us of MFMA work, so the bytes in flight per CU are what sets the speed).
     auto koff_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * s]); };
     int d_t = __builtin_amdgcn_readfirstlane(stab[1]);
-    issue_halo((d_t >> 9) & 7, d_t >> 12);
+    issue_halo((d_t >> 9) & 7, (d_t >> 12) & 15);
 #pragma unroll
     for (int a = 0; a < RING - 1; ++a)
         if (a < p.nsteps) issue_b(koff_of(a), a);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void head_entry_halo_kernel(const HeadHalo
         }
         if (s + 1 < p.nsteps && ((n_t >> 8) & 1)) {
             __builtin_amdgcn_s_barrier();  // group switch: every wave is done with the halo before it is replaced
-            issue_halo((n_t >> 9) & 7, n_t >> 12);
+            issue_halo((n_t >> 9) & 7, (n_t >> 12) & 15);
             fresh_halo = true;
             if (p.stamps) a_sw += __builtin_amdgcn_s_memtime() - t2;
         }
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(NW * 64) void head_entry_halo_kernel(const HeadHalo
 // group reads its fragments in the open.
 constexpr int HB_HW = 18, HB_ROWS = 324, HB_PIECES = 41, HB_HALO_BYTES = 41 * 1024, HB_RING = 4;
 
+template <bool STAMPS>
 __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHaloParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const hb = smem;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
             int row = piece * 8 + lrow;
             row = row < HB_ROWS ? row : HB_ROWS - 1;
             const int i = row / HB_HW, j = row - i * HB_HW;
-            const int c_log = (lane & 7) ^ (row & 6);
+            const int c_log = (lane & 7) ^ (j & 6);   // keyed by the halo COLUMN: see load_frags
             const half_t* g;
             if (src < 4) {
                 int yy = 2 * (ly0 - 1 + i) + (src >> 1) + p.c2_ring, xx = 2 * (lx0 - 1 + j) + (src & 1) + p.c2_ring;
@@ -318,14 +319,19 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
     __syncthreads();
     auto koff_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * s]); };
     auto desc_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * (s < p.nsteps ? s : p.nsteps - 1) + 1]); };
-    // fragments of (tap offset, ring stage, half kk)
+    // fragments of (tap offset, ring stage, half kk).  PMC (SQ_INSTS_VALU / SQ_INSTS_MFMA) put this kernel at 3.7 vector instructions
+    // per MFMA -- 8 issue cycles for the MFMA + 15 for VALU against the 16 cycles the MFMA occupies the pipe: the waves were
+    // issue-bound, and most of it was address arithmetic of these reads (row = base + tap, row * 128, (row & 6) ^ chunk, shift,
+    // add: six instructions per read).  Now: the 16-byte chunks of a halo row are XOR-swizzled by the row's halo COLUMN x (rows of
+    // one lane group are consecutive columns, so this is as conflict-free as the row key), x = fr + (tap column) is the same for
+    // the lane's four pixels, and those are 18 rows = 2304 bytes apart: ONE address per half step, four reads at immediate offsets.
+    const int a_lane_off = ((w * 4) * HB_HW + fr) * 128;
     auto load_frags = [&](int tapoff, int stage, int kk, half8 (&af)[4], half8 (&bf)[4]) {
         const char* sb = bring + stage * HE_BSTAGE;
+        const int dx = (tapoff >> 16) & 3;   // the tap's halo column offset, wave-uniform (bits 16-17 of the step descriptor)
+        const char* pa = hb + a_lane_off + (tapoff & 0xff) * 128 + (((fq + 4 * kk) ^ ((fr + dx) & 6)) << 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int hrow = hbase[j] + tapoff;
-            af[j] = *(const half8*)(hb + hrow * 128 + (((fq + 4 * kk) ^ (hrow & 6)) << 4));
-        }
+        for (int j = 0; j < 4; ++j) af[j] = *(const half8*)(pa + j * (HB_HW * 128));
 #pragma unroll
         for (int i = 0; i < 4; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + (((fq + 4 * kk) ^ bswz) << 4));
     };
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
     auto raw_k = [&](int s) { return stab[2 * (s < p.nsteps ? s : p.nsteps - 1)]; };
     auto raw_t = [&](int s) { return stab[2 * (s < p.nsteps ? s : p.nsteps - 1) + 1]; };
     int d_t = __builtin_amdgcn_readfirstlane(raw_t(0)), n_t = __builtin_amdgcn_readfirstlane(raw_t(1));
-    issue_halo((d_t >> 9) & 7, d_t >> 12);
+    issue_halo((d_t >> 9) & 7, (d_t >> 12) & 15);
 #pragma unroll
     for (int a = 0; a < HB_RING - 1; ++a)
         if (a < p.nsteps) issue_b(koff_of(a), a);
@@ -346,17 +352,17 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
     bool fresh_halo = true;
     int stage = 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, a_wait = 0, a_comp = 0, a_sw = 0, t_begin = 0;
-    if (p.stamps) t_begin = __builtin_amdgcn_s_memtime();
+    if constexpr (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < p.nsteps; ++s) {
-        if (p.stamps) t0 = __builtin_amdgcn_s_memtime();
+        if constexpr (STAMPS) t0 = __builtin_amdgcn_s_memtime();
         // all waves: weights of steps s and s+1 landed (only the newest ring stage may still be in flight); a fresh halo is newer
         // than every weight load, so it needs the full wait
         if (fresh_halo || s + 2 >= p.nsteps) he_wait_vmcnt<0>(); else he_wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
-        if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+        if constexpr (STAMPS) t1 = __builtin_amdgcn_s_memtime();
         const int k3 = __builtin_amdgcn_readfirstlane(v_k3), nn_t = __builtin_amdgcn_readfirstlane(v_t2);
         if (s + HB_RING - 1 < p.nsteps) issue_b(k3, (stage + HB_RING - 1) & 3);
-        const int tapoff = d_t & 0xff;
+        const int tapoff = d_t;
         const bool next_same_group = s + 1 < p.nsteps && !((n_t >> 8) & 1);
         if (!have_frags) load_frags(tapoff, stage, 0, fa[0], fb[0]);
         // half 0: prefetch half 1 of this step
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         __builtin_amdgcn_sched_barrier(0);
         // half 1: prefetch half 0 of the next step (same halo group only), then the descriptors of the steps after it
-        if (next_same_group) load_frags(n_t & 0xff, (stage + 1) & 3, 0, fa[0], fb[0]);
+        if (next_same_group) load_frags(n_t, (stage + 1) & 3, 0, fa[0], fb[0]);
         v_k3 = raw_k(s + HB_RING);
         v_t2 = raw_t(s + 3);
 #pragma unroll
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
         __builtin_amdgcn_sched_barrier(0);
         have_frags = next_same_group;
         fresh_halo = false;
-        if (p.stamps) {
+        if constexpr (STAMPS) {
             asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
             t2 = __builtin_amdgcn_s_memtime();
             a_wait += t1 - t0;
@@ -387,16 +393,16 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
         }
         if (s + 1 < p.nsteps && !next_same_group) {
             __builtin_amdgcn_s_barrier();  // group switch: every wave is done with the halo before it is replaced
-            issue_halo((n_t >> 9) & 7, n_t >> 12);
+            issue_halo((n_t >> 9) & 7, (n_t >> 12) & 15);
             fresh_halo = true;
-            if (p.stamps) a_sw += __builtin_amdgcn_s_memtime() - t2;
+            if constexpr (STAMPS) a_sw += __builtin_amdgcn_s_memtime() - t2;
         }
         d_t = n_t;
         n_t = nn_t;
         stage = (stage + 1) & 3;
     }
 
-    if (p.stamps && tid == 0) {
+    if (STAMPS && tid == 0) {
         unsigned long long* o = p.stamps + (int64_t)blockIdx.x * 4;
         o[0] = a_wait; o[1] = a_comp; o[2] = a_sw; o[3] = __builtin_amdgcn_s_memtime() - t_begin;
     }
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
 
 }  // namespace
 
-// Step table of one interior class (py, px): entries {k offset into the [64][K] class matrix, tapoff | first<<8 | src<<9 | chunk<<12}.
+// Step table of one interior class (py, px): entries {k offset into the [64][K] class matrix, tapoff | first<<8 | src<<9 | chunk<<12 | tap column<<16}.
 // nch1 = C2 channels / 64.  Returns the number of steps (25*nch1 + 36).
 int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36)*2] */) {
     int s = 0;
@@ -448,7 +454,7 @@ int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36
                     const int a = ty - 2 * uy, b = tx - 2 * ux;
                     if (a * 2 + b != plane) continue;
                     out[2 * s] = (dy * 5 + dx) * c2ch + ch * 64;
-                    out[2 * s + 1] = ((uy + 1) * 18 + (ux + 1)) | ((first ? 1 : 0) << 8) | (plane << 9) | (ch << 12);
+                    out[2 * s + 1] = ((uy + 1) * 18 + (ux + 1)) | ((first ? 1 : 0) << 8) | (plane << 9) | (ch << 12) | ((ux + 1) << 16);
                     first = false;
                     ++s;
                 }
@@ -456,7 +462,7 @@ int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36
     for (int ch = 0; ch < 4; ++ch)
         for (int ij = 0; ij < 9; ++ij) {
             out[2 * s] = 25 * c2ch + ij * 256 + ch * 64;
-            out[2 * s + 1] = ((ij / 3) * 18 + (ij % 3)) | ((ij == 0 ? 1 : 0) << 8) | (4 << 9) | (ch << 12);
+            out[2 * s + 1] = ((ij / 3) * 18 + (ij % 3)) | ((ij == 0 ? 1 : 0) << 8) | (4 << 9) | (ch << 12) | ((ij % 3) << 16);
             ++s;
         }
     return s;
@@ -482,7 +488,8 @@ int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int ns
         if (lds256 < 256 * HE_EPI_ROW) return -2303;
         static bool attr256 = false;
         if (!attr256) {
-            hipError_t e = hipFuncSetAttribute((const void*)head_entry_halo256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)head_entry_halo256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_entry_halo256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return -(int)e;
             attr256 = true;
         }
@@ -492,7 +499,7 @@ int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int ns
             unsigned long long* dev = nullptr;
             if (hipMalloc(&dev, (size_t)grid256 * 32) != hipSuccess) return -2304;
             p.stamps = dev;
-            hipLaunchKernelGGL(head_entry_halo256_kernel, dim3(grid256), dim3(256), lds256, stream, p);
+            hipLaunchKernelGGL(head_entry_halo256_kernel<true>, dim3(grid256), dim3(256), lds256, stream, p);
             (void)hipStreamSynchronize(stream);
             unsigned long long* h = (unsigned long long*)malloc((size_t)grid256 * 32);
             (void)hipMemcpy(h, dev, (size_t)grid256 * 32, hipMemcpyDeviceToHost);
@@ -504,7 +511,7 @@ int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int ns
             (void)hipFree(dev);
             return 0;
         }
-        hipLaunchKernelGGL(head_entry_halo256_kernel, dim3(grid256), dim3(256), lds256, stream, p);
+        hipLaunchKernelGGL(head_entry_halo256_kernel<false>, dim3(grid256), dim3(256), lds256, stream, p);
         return -(int)hipGetLastError();
     }
     static const int ring = [] { const char* e = getenv("VTD_HEAD_HALO_RING"); const int r = e ? atoi(e) : 2; return (r == 2 || r == 3) ? r : 2; }();
