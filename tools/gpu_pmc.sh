@@ -14,6 +14,6 @@ for d in ("gpurun_out/pmc_sq/p1","gpurun_out/pmc_sq/p2"):
         for r in csv.DictReader(open(path)):
             acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in acc.items():
-        if any(x in k for x in ("head_entry","persistent","conv_igemm_kernel<256, 128","stem_pool")):
+        if any(x in k for x in ("head_entry","persistent","conv_igemm_kernel<256, 128","conv_igemm_kernel<128, 64, 2, 2, 2","stem_pool","head_tail","preprocess")):
             print(k, {c: round(sum(x)/len(x)) for c,x in v.items()}, "launches", len(next(iter(v.values()))))
 PY

@@ -8,22 +8,25 @@
 //     tile; 14 % halo recompute) and stages the 35x40-pixel NHWC4 input patch (11 KB) in LDS once;
 //   * K is walked as 7 kernel rows x (8 taps x 4 ch): the 8 halfs a lane feeds to v_mfma_f32_16x16x32_f16 are 2
 //     neighbouring input pixels = one aligned 16-byte LDS read, no im2col buffer is ever built;
-//   * all 64x224 folded weights live in registers (28 fragments / lane) for the whole persistent loop;
+//   * all 64x224 folded weights live in registers (28 fragments / lane) for the whole persistent loop; the BN shift starts
+//     the accumulators;
 //   * the conv tile goes to LDS as fp16 after bias+ReLU (out-of-image positions forced to 0: post-ReLU values are
 //     >= 0, so a zero is as good as -inf for the pool's padding), the 3x3/s2 max runs from LDS and only the pooled
 //     160x160x64 map is written to HBM (105 MB instead of 420 + 105 MB).
-// The next tile's patch is fetched into registers before the MFMA loop and parked in the other LDS buffer after it.
+// Patches arrive by LDS-DMA through a 3-deep ring, two tiles ahead of the maths (round 1 fetched one tile ahead into registers
+// and consumed it right after the MFMA loop: the launch ran at the load latency), and each XCD sweeps its own eighth of the tiles.
 #include "vtd_common.h"
 
 namespace {
 
 constexpr int SP_PT_ROWS = 7, SP_PT_COLS = 8;         // pooled pixels per tile
 constexpr int SP_CT_ROWS = 15, SP_CT_COLS = 17;       // conv outputs per tile
-constexpr int SP_PATCH_ROWS = 37, SP_PATCH_COLS = 40; // input pixels staged (35 used + 2 rows touched by the idle 256th row)
-constexpr int SP_PATCH_BYTES = SP_PATCH_ROWS * SP_PATCH_COLS * 8;
+constexpr int SP_PATCH_COLS = 40;                     // input pixels per staged patch row (35 rows used)
+constexpr int SP_PIECES = 12;                         // 1 KB LDS-DMA pieces per patch: 35 rows x 20 units of 16 bytes = 700 units
+constexpr int SP_PATCH_BYTES = SP_PIECES * 1024;      // (the 256th, idle GEMM row reads rows 35, 36: still inside)
+constexpr int SP_NST = 3;                             // patch ring depth
 constexpr int SP_CT_PITCH = 144;                      // bytes per conv pixel in LDS (64 ch fp16 + 16 pad)
-constexpr int SP_WREG_ROWS = 5;                       // kernel rows whose weights stay in registers
-constexpr int SP_UNITS = 35 * 20;                     // 16-byte units of a patch that are actually loaded
+constexpr int SP_LDS = SP_NST * SP_PATCH_BYTES + 256 * SP_CT_PITCH + 256;
 
 struct StemPoolParams {
     const half_t* in;    // [n][in_hp][in_wp][4] fp16, ring 3
@@ -34,6 +37,14 @@ struct StemPoolParams {
     int tiles_x, tiles_y, total_tiles;
 };
 
+template <int N>
+__device__ __forceinline__ void sp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that orders LDS only (__syncthreads would also sit out every global load and store in flight)
+__device__ __forceinline__ void sp_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ void sp_tile_coords(const StemPoolParams& p, int tile, int& img, int& py0, int& px0) {
     const int per_img = p.tiles_x * p.tiles_y;
     img = tile / per_img;
@@ -43,34 +54,38 @@ __device__ __forceinline__ void sp_tile_coords(const StemPoolParams& p, int tile
     px0 = (r - ty * p.tiles_x) * SP_PT_COLS;
 }
 
-// unit u of the patch of tile (img, py0, px0): 2 input pixels, zero outside the padded image
-__device__ __forceinline__ uint4 sp_fetch_unit(const StemPoolParams& p, int img, int py0, int px0, int u) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (u < SP_UNITS) {
-        const int prow = u / 20, c2 = u - prow * 20;
-        const int iy = 4 * py0 - 2 + prow, ix = 4 * px0 - 2 + 2 * c2;
-        if (iy >= 0 && iy < p.in_hp && ix >= 0 && ix + 1 < p.in_wp)
-            v = *(const uint4*)(p.in + (((int64_t)img * p.in_hp + iy) * p.in_wp + ix) * 4);
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char patch[2][SP_PATCH_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char ctile[256 * SP_CT_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char wlds[(7 - SP_WREG_ROWS) * 4 * 64 * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    unsigned char* const ring = sp_smem;                                 // [SP_NST][SP_PATCH_BYTES]
+    unsigned char* const ctile = sp_smem + SP_NST * SP_PATCH_BYTES;      // [256][SP_CT_PITCH]
+    float* const bias_lds = (float*)(ctile + 256 * SP_CT_PITCH);         // [64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
 
-    // folded weights: resident in registers for every tile this workgroup processes
-    // (kernel rows 0..SP_WREG_ROWS-1 in VGPRs, the rest in LDS, so that the 256-VGPR budget of 2 waves/SIMD holds)
-    half8 wreg[SP_WREG_ROWS][4];
+    // Tile order.  Consecutive workgroup ids sit on different XCDs, each with its own L2: with tile = blockIdx + k * grid the
+    // neighbours that share a patch halo were always fetched through different L2s (PMC: 221 MB read for a 105 MB input).  Each
+    // XCD now owns a contiguous eighth of the tiles and its workgroups sweep it side by side, so halos are L2 hits.
+    int first, stride, last;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+        const int lo = (int)(((int64_t)p.total_tiles * xcd) >> 3);
+        last = (int)(((int64_t)p.total_tiles * (xcd + 1)) >> 3);
+        first = lo + (blockIdx.x >> 3);
+        stride = per;
+    } else {
+        first = blockIdx.x; stride = gridDim.x; last = p.total_tiles;
+    }
+    if (first >= last) return;
+    const int nt = (last - first + stride - 1) / stride;
+
+    // folded weights: all 28 fragments stay in registers for every tile this workgroup processes
+    half8 wreg[7][4];
 #pragma unroll
-    for (int ky = 0; ky < SP_WREG_ROWS; ++ky)
+    for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
         for (int i = 0; i < 4; ++i) wreg[ky][i] = *(const half8*)(p.w + ((ky * 4 + i) * 64 + lane) * 8);
-    for (int u = tid; u < (7 - SP_WREG_ROWS) * 4 * 64; u += 256)
-        *(half8*)(wlds + u * 16) = *(const half8*)(p.w + (SP_WREG_ROWS * 4 * 64 + u) * 8);
+    if (tid < 64) bias_lds[tid] = p.bias[tid];
     // this lane's four GEMM rows (conv pixels of the patch) -> LDS byte offset of tap (ky=0, kx=2fq)
     int a_off[4];
 #pragma unroll
@@ -79,46 +94,50 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         const int c_row = pix / SP_CT_COLS, c_col = pix - c_row * SP_CT_COLS;
         a_off[j] = ((2 * c_row) * SP_PATCH_COLS + 2 * c_col + 2 * fq) * 8;
     }
-
-    // rows 35, 36 of both patch buffers are only read by the idle 256th GEMM row: keep them defined
-    for (int i = tid; i < 2 * 2 * SP_PATCH_COLS * 2; i += 256) {
-        const int b = i / (2 * SP_PATCH_COLS * 2), r = i - b * (2 * SP_PATCH_COLS * 2);
-        *(uint32_t*)(patch[b] + 35 * SP_PATCH_COLS * 8 + r * 4) = 0u;
+    // The patch arrives by LDS-DMA, SP_NST-1 tiles ahead: wave wv brings pieces wv, wv+4, wv+8 (64 units of 2 pixels each, laid
+    // out [patch row][20 units]).  Units past the 700th repeat the last row.  Coordinates outside the padded image are CLAMPED,
+    // not zero-filled: such pixels only ever feed conv outputs outside the conv map, which the epilogue replaces by 0, or the
+    // zero weights of the eighth tap -- and whatever is read instead is a finite fp16 of the same tensor.
+    int u_row[3], u_col[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int u = (wv + 4 * k) * 64 + lane;
+        u = u < 700 ? u : 699;
+        u_row[k] = u / 20;
+        u_col[k] = 2 * (u - u_row[k] * 20);
     }
-
-    int tile = blockIdx.x;
-    if (tile >= p.total_tiles) return;
-    int img, py0, px0;
-    sp_tile_coords(p, tile, img, py0, px0);
-    {
-        uint4 v[3];
+    auto issue = [&](int tile, int stage) {
+        int img, py0, px0;
+        sp_tile_coords(p, __builtin_amdgcn_readfirstlane(tile), img, py0, px0);
+        const half_t* base = p.in + (int64_t)img * p.in_hp * p.in_wp * 4;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = sp_fetch_unit(p, img, py0, px0, tid + k * 256);
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (tid + k * 256 < SP_UNITS) *(uint4*)(patch[0] + (tid + k * 256) * 16) = v[k];
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (; tile < p.total_tiles; tile += gridDim.x) {
-        // prefetch the next tile's patch into registers (lands while the matrix cores work)
-        const int ntile = tile + gridDim.x;
-        const bool has_next = ntile < p.total_tiles;
-        int nimg = 0, npy0 = 0, npx0 = 0;
-        uint4 nv[3];
-        if (has_next) {
-            sp_tile_coords(p, ntile, nimg, npy0, npx0);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) nv[k] = sp_fetch_unit(p, nimg, npy0, npx0, tid + k * 256);
+        for (int k = 0; k < 3; ++k) {
+            int iy = 4 * py0 - 2 + u_row[k], ix = 4 * px0 - 2 + u_col[k];
+            iy = iy < 0 ? 0 : iy > p.in_hp - 1 ? p.in_hp - 1 : iy;
+            ix = ix < 0 ? 0 : ix > p.in_wp - 2 ? p.in_wp - 2 : ix;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(base + (iy * p.in_wp + ix) * 4),
+                                             (VTD_AS3 void*)(ring + stage * SP_PATCH_BYTES + (wv + 4 * k) * 1024), 16, 0, 0);
         }
+    };
 
-        floatx4 acc[4][4];  // [cout tile][pixel fragment]
+    issue(first, 0);
+    if (nt > 1) { issue(first + stride, 1); sp_wait_vmcnt<3>(); } else sp_wait_vmcnt<0>();
+    sp_lds_barrier();
+
+    int st = 0;
+    for (int k = 0; k < nt; ++k) {
+        const int tile = first + k * stride;
+        int img, py0, px0;
+        sp_tile_coords(p, __builtin_amdgcn_readfirstlane(tile), img, py0, px0);
+        // the stage tile k-1 was read from is free (barrier at the end of the last iteration): tile k+2 goes there
+        if (k + 2 < nt) issue(tile + 2 * stride, st == 0 ? SP_NST - 1 : st - 1);
+
+        floatx4 acc[4][4];  // [cout tile][pixel fragment]; the BN shift rides in the accumulator
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* pb = patch[cur];
+            for (int j = 0; j < 4; ++j) acc[i][j] = *(const floatx4*)(bias_lds + i * 16 + fq * 4);
+        const unsigned char* pb = ring + st * SP_PATCH_BYTES;
         // software pipeline by hand: the fragments of kernel row ky+1 are read while row ky multiplies; the scheduling
         // barriers stop the compiler from hoisting all 28 LDS reads (which would blow the register budget)
         half8 af[2][4];
@@ -130,56 +149,40 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) af[(ky + 1) & 1][j] = *(const half8*)(pb + a_off[j] + (ky + 1) * (SP_PATCH_COLS * 8));
             }
-            if (ky < SP_WREG_ROWS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ky < SP_WREG_ROWS ? ky : 0][i], af[ky & 1][j], acc[i][j], 0, 0, 0);
-            } else {
-                half8 wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *(const half8*)(wlds + (((ky - SP_WREG_ROWS) * 4 + i) * 64 + lane) * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[ky & 1][j], acc[i][j], 0, 0, 0);
-            }
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ky][i], af[ky & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        if (has_next) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (tid + k * 256 < SP_UNITS) *(uint4*)(patch[cur ^ 1] + (tid + k * 256) * 16) = nv[k];
-        }
-
-        // bias + ReLU, zero outside the conv map, fp16 -> LDS conv tile (lane: 4 consecutive channels of one pixel)
+        // ReLU (packed, after the fp16 convert), zero outside the conv map, -> LDS conv tile (lane: 4 consecutive channels of one pixel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pix = wv * 64 + j * 16 + fr;
             const int c_row = pix / SP_CT_COLS, c_col = pix - c_row * SP_CT_COLS;
             const int cy = 2 * py0 - 1 + c_row, cx = 2 * px0 - 1 + c_col;
             const bool valid = cy >= 0 && cy < p.conv_h && cx >= 0 && cx < p.conv_w;
-            unsigned char* dst = ctile + (wv * 64 + j * 16 + fr) * SP_CT_PITCH + fq * 8;
+            unsigned char* dst = ctile + pix * SP_CT_PITCH + fq * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const floatx4 b4 = *(const floatx4*)(p.bias + i * 16 + fq * 4);
                 half4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[i][j][e] + b4[e];
-                    hv[e] = (half_t)((valid && v > 0.f) ? v : 0.f);
-                }
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[i][j][e];
+                hv = __builtin_elementwise_max(hv, half4{0, 0, 0, 0});
+                if (!valid) hv = half4{0, 0, 0, 0};
                 *(half4*)(dst + i * 32) = hv;
             }
         }
-        __syncthreads();
+        sp_lds_barrier();
 
         // 3x3/s2 max over the conv tile: item = (pooled pixel, 8-channel group)
         for (int item = tid; item < SP_PT_ROWS * SP_PT_COLS * 8; item += 256) {
-            const int q = item >> 3, cg = item & 7;
-            const int qy = q >> 3, qx = q & 7;
+            // A wave's 64 items are one pooled row: 8 pixels x 8 channel groups.  Which lane takes which matters: ds_read_b128 is
+            // served in four fixed 16-lane groups and with cg = lane & 7 each group hit its banks 2.75 times (11 LDS cycles per
+            // read, SQ_LDS_BANK_CONFLICT); with this assignment the 16 chunks of a group fall on 16 different bank quads.
+            const int qy = item >> 6, cg = (item >> 2) & 7;
+            const int qx = ((item >> 5) & 1) | ((item & 3) << 1);
             const int py = py0 + qy, px = px0 + qx;
             if (py < p.pool_h && px < p.pool_w) {
                 const unsigned char* src = ctile + ((2 * qy) * SP_CT_COLS + 2 * qx) * SP_CT_PITCH + cg * 16;
@@ -189,16 +192,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
                         if (r == 0 && s == 0) continue;
-                        const half8 v = *(const half8*)(src + (r * SP_CT_COLS + s) * SP_CT_PITCH);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+                        m = __builtin_elementwise_max(m, *(const half8*)(src + (r * SP_CT_COLS + s) * SP_CT_PITCH));
                     }
                 *(half8*)(p.out + (((int64_t)img * p.out_hp + py + p.out_ring) * p.out_wp + px + p.out_ring) * 64 + cg * 8) = m;
             }
         }
-        __syncthreads();
-        cur ^= 1;
-        img = nimg; py0 = npy0; px0 = npx0;
+        // Tile k+1 must be in LDS for everyone after the barrier below.  Loads land in order, so it has landed once at most the 3
+        // loads of tile k+2 are outstanding; the pooled stores just issued share the counter and retire out of order with loads,
+        // but they are YOUNGER than tile k+1's loads and can only lengthen this wait.
+        if (k + 2 < nt) sp_wait_vmcnt<3>(); else sp_wait_vmcnt<0>();
+        sp_lds_barrier();
+        st = st + 1 == SP_NST ? 0 : st + 1;
     }
 }
 
@@ -233,7 +237,13 @@ int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half
     p.tiles_y = (out.h + SP_PT_ROWS - 1) / SP_PT_ROWS;
     p.total_tiles = n * p.tiles_x * p.tiles_y;
     const int grid = p.total_tiles < 512 ? p.total_tiles : 512;  // 2 resident workgroups per CU, persistent over tiles
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), 0, stream, p);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+        if (ea != hipSuccess) return -(int)ea;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), SP_LDS, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
