@@ -194,6 +194,34 @@ def test_dbnet_halo_conv_forced(hip, monkeypatch):
     assert not any("conv_halo" in n for n in outs["0"][2])
 
 
+def test_fpn_lateral_streaming_kernel_bit_identical(hip, monkeypatch):
+    """pointwise.hip (the C3 lateral 128 -> 256 + top-down add as one streaming launch) forced, at a batch that gives whole
+    and wrapped 64-pixel tiles: the probability map and the head map are BIT-identical to the implicit-GEMM path (same K order,
+    same bias / residual order, one fp16 rounding), and within the usual tolerance of the fp32 oracle."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(77))
+    ref = onets.dbnet_forward(x, sd, "resnet18")
+    outs = {}
+    for mode in ("1", None):
+        if mode: monkeypatch.setenv("VTD_FORCE_POINTWISE", mode)
+        else: monkeypatch.delenv("VTD_FORCE_POINTWISE", raising=False)
+        eng = DetectorEngine("resnet18", sd, max_batch=3)
+        try:
+            prob = eng.forward(x)["probability"].cpu().numpy()
+            h1 = eng.read_tap("head1", 3)
+            names = [r[0] for r in detector_profile(eng)]
+        finally:
+            eng.close()
+        outs[mode] = (prob, h1, names)
+    assert sum("pointwise128" in n for n in outs["1"][2]) == 1, outs["1"][2]
+    if any("pointwise128" in n for n in outs[None][2]):
+        pytest.skip("the shipped table already names the streaming kernel for this shape: nothing to compare it with")
+    assert np.array_equal(outs["1"][1], outs[None][1])
+    assert np.array_equal(outs["1"][0], outs[None][0])
+    assert float(np.abs(outs["1"][0] - ref["probability"].numpy()).max()) <= 2e-3
+
+
 def test_dbnet_batch_independence_and_threshold_branch(r18):
     eng, sd = r18
     x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(10))

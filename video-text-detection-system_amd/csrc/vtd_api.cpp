@@ -32,6 +32,8 @@ int vtd_launch_head_entry_pair(const ConvParams& c, const int* half_steps_dev, c
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
 bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
+bool vtd_pointwise128_supported(const ConvParams& c);
+int vtd_launch_pointwise128(const ConvParams& c, hipStream_t stream);
 void vtd_head_tail_pack_w1(const half_t* w1_gemm, half_t* packed);
 void vtd_head_tail_pack_w2(const float* w2, half_t* packed);
 int vtd_launch_head_tail(const TensorDesc& in, const half_t* w1, const float* bias1, const half_t* w2, float b2, float* out, int n,
@@ -163,6 +165,7 @@ static const int kHaloC64Cfg = 101;  // persistent resident-weight variant for 6
 static const int kHalo64Cfg = 104;  // second-generation halo kernel: 64 output channels per workgroup, hand-pipelined
 static const int kHeadEntryHalo256Cfg = 103;  // same, 16x16 pixel blocks with 64x64 register tiles (hand-pipelined)
 static const int kHeadEntryPairCfg = 105;  // two 16x16 blocks per workgroup on one weight ring, 32-channel halos prefetched two groups ahead
+static const int kPointwiseCfg = 106;  // streaming 1x1 convolution 128 -> 256 with the top-down add (pointwise.hip): the C3 lateral
 static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
@@ -186,6 +189,7 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
         if (!vtd_conv_halo_supported(p, &bn, &tw)) return ERR_GEOMETRY;
         return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : cfg == kHalo64Cfg ? 2 : bn, tw, s);
     }
+    if (cfg == kPointwiseCfg) return vtd_launch_pointwise128(p, s);
     return vtd_launch_conv(p, cfg, s);
 }
 
@@ -256,6 +260,17 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
             // (vtd_amd/tuning/gfx950.txt, chosen by in-situ measurement of the whole pipeline: tools/tune_table.py) lacks.
             (void)best_gathered;
             if (!rc && ms < best) { best = ms; best_id = vcfg; }
+        }
+    }
+    if (!rc && vtd_pointwise128_supported(p)) {
+        if (!(rc = vtd_launch_pointwise128(p, s))) {
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3 && !rc; ++rep) rc = vtd_launch_pointwise128(p, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = ERR_ARG;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (!rc && ms < best) { best = ms; best_id = kPointwiseCfg; }
         }
     }
     int hbn = 0, htw = 0;
@@ -380,6 +395,7 @@ static bool config_valid_for(const ConvOp& c, int n, int cfg) {
         if (!vtd_conv_halo_supported(p, &bn, &tw)) return false;
         return cfg != kHaloC64Cfg || vtd_conv_halo_c64_supported(p, tw);
     }
+    if (cfg == kPointwiseCfg) return vtd_pointwise128_supported(p);
     return cfg >= 0 && cfg < vtd_conv_num_configs() && vtd_conv_config_valid(p, cfg);
 }
 
@@ -390,6 +406,10 @@ static int choose_config(ModelBase* m, const ConvOp& c, int n, hipStream_t s, in
     auto it = m->tuning.find(key);
     // test switches that pin a kernel variant (VTD_FORCE_CLASSED_CFG, VTD_FORCE_HALO) are honoured by the contest: they outrank the table
     const bool forced = std::getenv("VTD_FORCE_CLASSED_CFG") || std::getenv("VTD_FORCE_HALO");
+    if (const char* fp = std::getenv("VTD_FORCE_POINTWISE"); fp && fp[0] == '1' && config_valid_for(c, n, kPointwiseCfg)) {
+        *cfg = kPointwiseCfg;  // tests: the streaming 1x1 kernel wherever it applies, every other slot as usual
+        return 0;
+    }
     if (!forced && it != m->tuning.end() && config_valid_for(c, n, it->second)) {
         *cfg = it->second;
         return 0;
@@ -1374,6 +1394,8 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
         else if (cfg == kHeadEntryHaloCfg)
             std::snprintf(name, name_cap, "head_entry_halo M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
                           "next slot)", c.ho * c.wo, c.cout, c.K);
+        else if (cfg == kPointwiseCfg)
+            std::snprintf(name, name_cap, "pointwise128 1x1%s streaming M/img=%d N=%d K=%d", c.has_res ? "+top-down add" : "", c.ho * c.wo, c.cout, c.K);
         else if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg)
             std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : cfg == kHalo64Cfg ? "64" : "",
                           c.ho * c.wo, c.cout, c.K);
