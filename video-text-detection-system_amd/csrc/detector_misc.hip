@@ -27,6 +27,7 @@ struct PreParams {
     const int* yk;          // [640][ksy]
     int H, W, ksx, ksy;
     int max_rows;           // LDS rows reserved per workgroup
+    unsigned quads_magic;   // fast path: ceil(2^32 / (W / 4))
 };
 
 __device__ __forceinline__ uint8_t clip8_22(int v) {
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
     const int raw_pitch = p.W + KSX;
     uint32_t* const raw = rows + p.max_rows * PRE_OUT;
     int* const ytab = (int*)(raw + PRE_CHUNK * raw_pitch);
+    half_t* const lut = (half_t*)(ytab + PRE_TY * (2 + KSY));  // [3][256]: normalised value of every 8-bit level, per output channel
     const int oy0 = blockIdx.x * PRE_TY;
     const int img = blockIdx.y;
     const int y_first = p.yb[2 * oy0];
@@ -155,6 +157,13 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
     }
     // zero the KSX padding pixels behind every raw row once (read with zero weights only, but they must be defined)
     for (int i = tid; i < PRE_CHUNK * KSX; i += 256) raw[(i / KSX) * raw_pitch + p.W + (i % KSX)] = 0u;
+    {   // The resampled pixel is an 8-bit level, so (v / 255 - mean) / std has 256 possible values per channel: evaluate the
+        // reference's expression (two IEEE divisions, ~25 instructions) once per level instead of once per pixel.
+        const float mean[3] = {0.485f, 0.456f, 0.406f};
+        const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lut[c * 256 + tid] = (half_t)(((float)tid / 255.0f - mean[c]) / stdv[c]);
+    }
 
     const int quads = p.W >> 2;  // 4 pixels = 12 bytes = 3 dwords (W % 4 == 0 on this path)
     // raw rows travel HBM -> registers -> LDS; the registers of chunk c+1 are loaded before chunk c is resampled, so the
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
         for (int it = 0; it < MAXIT; ++it) {
             const int i = tid + it * 256;
             if (i < nr * quads) {
-                const int rr = i / quads, q = i - rr * quads;
+                const int rr = (int)__umulhi((unsigned)i, p.quads_magic), q = i - rr * quads;  // i / quads (exact: i * quads < 2^32)
                 const uint32_t* g = (const uint32_t*)(src + (int64_t)(y_first + r0 + rr) * row_bytes) + q * 3;
                 stg[it][0] = g[0]; stg[it][1] = g[1]; stg[it][2] = g[2];
             }
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
         for (int it = 0; it < MAXIT; ++it) {
             const int i = tid + it * 256;
             if (i < nr * quads) {
-                const int rr = i / quads, q = i - rr * quads;
+                const int rr = (int)__umulhi((unsigned)i, p.quads_magic), q = i - rr * quads;
                 const uint32_t d0 = stg[it][0], d1 = stg[it][1], d2 = stg[it][2];
                 uint4 px;
                 px.x = d0 & 0xffffffu;
@@ -198,15 +207,18 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
             for (int s = 0; s < 3; ++s) {
                 const int ox = tid + 256 * s;
                 if (ox < PRE_OUT) {
-                    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+                    // 8-bit level x 22-bit coefficient (bilinear: never negative): the 24-bit multiply-add runs at full rate, a
+                    // 32-bit integer multiply at a quarter of it (this loop was 135 v_mul_lo_u32 in the kernel's ISA)
+                    uint32_t s0 = 1u << 21, s1 = 1u << 21, s2 = 1u << 21;
 #pragma unroll
                     for (int t = 0; t < KSX; ++t) {
                         const uint32_t px = row[xmin[s] + t];
-                        s0 += (int)(px & 0xffu) * kx[s][t];
-                        s1 += (int)((px >> 8) & 0xffu) * kx[s][t];
-                        s2 += (int)(px >> 16) * kx[s][t];
+                        const uint32_t kt = (uint32_t)kx[s][t];
+                        s0 = __umul24(px & 0xffu, kt) + s0;
+                        s1 = __umul24((px >> 8) & 0xffu, kt) + s1;
+                        s2 = __umul24(px >> 16, kt) + s2;
                     }
-                    rows[(r0 + rr) * PRE_OUT + ox] = (uint32_t)clip8_22(s0) | ((uint32_t)clip8_22(s1) << 8) | ((uint32_t)clip8_22(s2) << 16);
+                    rows[(r0 + rr) * PRE_OUT + ox] = (uint32_t)clip8_22((int)s0) | ((uint32_t)clip8_22((int)s1) << 8) | ((uint32_t)clip8_22((int)s2) << 16);
                 }
             }
         }
@@ -214,40 +226,37 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
     }
 
     // vertical taps + normalise, 4 pixels per thread; input channel order is BGR, output RGB0
-    const float mean[3] = {0.485f, 0.456f, 0.406f};
-    const float stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int idx = tid; idx < PRE_TY * (PRE_OUT / 4); idx += 256) {
         const int ty = idx / (PRE_OUT / 4), g = idx - ty * (PRE_OUT / 4);
         const int oy = oy0 + ty;
         if (oy >= PRE_OUT) break;
         const int* yt = ytab + ty * (2 + KSY);
         const int ymin = yt[0] - y_first;
-        int acc[4][3];
+        uint32_t acc[4][3];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[q][c] = 1 << 21;
+            for (int c = 0; c < 3; ++c) acc[q][c] = 1u << 21;
 #pragma unroll
         for (int t = 0; t < KSY; ++t) {
-            const int kv = yt[2 + t];
+            const uint32_t kv = (uint32_t)yt[2 + t];
             // rows past the window carry kv == 0; clamp the row index so the read stays inside the buffer
             const int r = min(ymin + t, nrows - 1);
             const uint4 px = *(const uint4*)(rows + r * PRE_OUT + g * 4);
             const uint32_t pv[4] = {px.x, px.y, px.z, px.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[q][0] += (int)(pv[q] & 0xffu) * kv;
-                acc[q][1] += (int)((pv[q] >> 8) & 0xffu) * kv;
-                acc[q][2] += (int)(pv[q] >> 16) * kv;
+                acc[q][0] = __umul24(pv[q] & 0xffu, kv) + acc[q][0];
+                acc[q][1] = __umul24((pv[q] >> 8) & 0xffu, kv) + acc[q][1];
+                acc[q][2] = __umul24(pv[q] >> 16, kv) + acc[q][2];
             }
         }
         half8 o01, o23;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float b = (float)clip8_22(acc[q][0]), gch = (float)clip8_22(acc[q][1]), r = (float)clip8_22(acc[q][2]);
-            const half_t h0 = (half_t)((r / 255.0f - mean[0]) / stdv[0]);
-            const half_t h1 = (half_t)((gch / 255.0f - mean[1]) / stdv[1]);
-            const half_t h2 = (half_t)((b / 255.0f - mean[2]) / stdv[2]);
+            const half_t h0 = lut[clip8_22((int)acc[q][2])];        // R
+            const half_t h1 = lut[256 + clip8_22((int)acc[q][1])];  // G
+            const half_t h2 = lut[512 + clip8_22((int)acc[q][0])];  // B
             if (q < 2) { o01[q * 4] = h0; o01[q * 4 + 1] = h1; o01[q * 4 + 2] = h2; o01[q * 4 + 3] = (half_t)0.f; }
             else { o23[(q - 2) * 4] = h0; o23[(q - 2) * 4 + 1] = h1; o23[(q - 2) * 4 + 2] = h2; o23[(q - 2) * 4 + 3] = (half_t)0.f; }
         }
@@ -312,9 +321,10 @@ __global__ void maxpool_kernel(const PoolParams p) {
 
 int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* out, const int* xb, const int* xk, int ksx,
                           const int* yb, const int* yk, int ksy, int max_rows, hipStream_t stream) {
-    PreParams p{frames, out, xb, xk, yb, yk, H, W, ksx, ksy, max_rows};
+    PreParams p{frames, out, xb, xk, yb, yk, H, W, ksx, ksy, max_rows, 0u};
     if ((W & 3) == 0 && W <= 2048 && ksy == 5 && (ksx == 5 || ksx == 7)) {  // 720p / 1080p class sizes: the widened-pixel fast path
-        const int lds_fast = (max_rows * PRE_OUT + PRE_CHUNK * (W + ksx) + PRE_TY * (2 + ksy)) * 4;
+        const int lds_fast = (max_rows * PRE_OUT + PRE_CHUNK * (W + ksx) + PRE_TY * (2 + ksy)) * 4 + 3 * 256 * 2;
+        p.quads_magic = (unsigned)(((1ull << 32) + (W / 4) - 1) / (W / 4));
         if (lds_fast <= 160 * 1024) {
             static bool attr5 = false, attr7 = false;
             if (ksx == 5) {
