@@ -146,6 +146,8 @@ def main():
     from vtd_amd.engine import DeviceFrames, detector_profile
 
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if os.environ.get("VTD_BENCH_DET_PRIORITY") == "1":   # experiment: the caller's (detector) stream above the side streams
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -168,18 +168,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // One half K-step (32 deep) of MFMAs out of buffer `sb`; when LOADING, `nload` LDS-DMA instructions [j0, j0+nload) of
-    // K-step `lks` are issued BETWEEN the MFMAs: a global_load_lds costs the wave ~60-100 issue cycles, which hide
-    // behind the matrix pipe only if they are spread over it (back to back at the top of the step they cost as much
-    // as the step's MFMAs).  sched_group_barrier pins the interleave the source order asks for.
-    auto half_step = [&](const char* sb, int kk, auto nload_c, int lks, int lbuf, int j0) {
-        constexpr int nload = decltype(nload_c)::value;
+    // ---- main loop.  Software pipeline over HALF K-steps (32 deep), fragments double-buffered in registers:
+    //
+    //   iteration s:   read fragments (s, half 1) -> f[1]  |  MFMAs of (s, half 0) out of f[0]   + LDS-DMA
+    //                  wait: K-step s+1 landed; barrier B(s+1)
+    //                  read fragments (s+1, half 0) -> f[0] |  MFMAs of (s, half 1) out of f[1]  + LDS-DMA
+    //
+    // Every ds_read is issued one half-step before its MFMAs, so the LDS latency hides behind the matrix pipe of the SAME wave.
+    // (Round 1 read a half-step's 8 fragments and then multiplied: all waves of a workgroup leave the barrier together, read
+    // together and multiply together, so nobody covered anybody's ~250 read cycles: with every load removed the launches still
+    // took twice their MFMA time, tools/conv_experiment.sh.)  The barrier sits in the MIDDLE of a K-step: B(s+1) publishes K-step
+    // s+1 and, since every wave has by then finished reading both halves of K-step s, frees buffer s % STAGES for K-step
+    // s + STAGES.  With 3 stages those loads are spread over the MFMAs of the two half-steps after the barrier and have until
+    // B(s+3); with 2 stages they all leave right after the barrier and have one K-step, as before.
+    auto read_frags = [&](const char* sb, int kk, half8 (&af)[FM], half8 (&bf)[FN]) {
         const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
-        half8 af[FM], bf[FN];
 #pragma unroll
         for (int j = 0; j < FM; ++j) af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
 #pragma unroll
         for (int i = 0; i < FN; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + phys);
+    };
+    // the MFMAs of one half K-step out of (af, bf); `nload` LDS-DMA instructions [j0, j0 + nload) of K-step `lks` are issued BETWEEN
+    // them: a global_load_lds costs the wave ~60-100 issue cycles, which hide behind the matrix pipe only if they are spread over it
+    auto mfma_half = [&](const half8 (&af)[FM], const half8 (&bf)[FN], auto nload_c, int lks, int lbuf, int j0) {
+        constexpr int nload = decltype(nload_c)::value;
         constexpr int NM = FM * FN;
         int q = 0, issued = 0;
 #pragma unroll
@@ -188,53 +200,89 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             for (int j = 0; j < FM; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
                 ++q;
-                // spread the loads evenly: the k-th load goes after MFMA number (k+1)*NM/(nload+1)
                 if (issued < nload && q >= (issued + 1) * NM / (nload + 1)) {
                     issue_load(j0 + issued, lks, lbuf);
                     ++issued;
                 }
             }
-        // pin that order: fragment reads first, then MFMA groups with one LDS-DMA after each
-        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // DS read
-        pin_loads_between_mfmas<NM, nload>();
     };
 
     const int nk = p.K >> 6;
-    stage(0, 0);
-    if (STAGES == 3 && nk > 1) stage(1, 1);
-
-    int buf = 0;
     constexpr int L0 = (LOADS + 1) / 2, L1 = LOADS - L0;
-    const int nmain = nk - (STAGES - 1) > 0 ? nk - (STAGES - 1) : 0;
-    // steady state: K-step ks is consumed while K-step ks + STAGES - 1 is fetched
-    for (int ks = 0; ks < nmain; ++ks) {
-        if (STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // everyone's loads landed; everyone finished reading the buffer refilled below
-        int nb = buf + STAGES - 1;
-        nb = nb >= STAGES ? nb - STAGES : nb;
-        const int lks = ks + STAGES - 1;
+    constexpr int P2 = STAGES == 3 ? L1 : 0;      // loads issued under the MFMAs of half 0 (second part of K-step s+2)
+    constexpr int P4 = STAGES == 3 ? L0 : LOADS;  // loads issued after the barrier (first part of K-step s+3 / all of K-step s+2)
+    half8 fa[2][FM], fb[2][FN];
+
+    // prologue: K-steps 0 and 1 entirely, with 3 stages also the first part of K-step 2
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (STAGES == 3 && nk > 2) {
+        begin_step(2);
+#pragma unroll
+        for (int j = 0; j < L0; ++j) issue_load(j, 2, 2);
+    }
+    if (STAGES == 3 && nk > 2) wait_vmcnt<LOADS + L0>(); else if (nk > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, 0, fa[0], fb[0]);
+
+    // one iteration; HAS2 / HAS4: the loads of part 2 / part 4 exist (compile-time, so the load / MFMA interleave stays pinned)
+    auto iteration = [&](int s, int buf, auto has2_c, auto has4_c) {
+        constexpr bool HAS2 = decltype(has2_c)::value != 0, HAS4 = decltype(has4_c)::value != 0;
         const char* sb = smem + buf * STAGE;
-        if constexpr (STAGES == 3) {
-            // two K-steps of slack: spread the LDS-DMA issue over the whole step's MFMAs
-            begin_step(lks);
-            half_step(sb, 0, IntC<L0>{}, lks, nb, 0);
-            half_step(sb, 1, IntC<L1>{}, lks, nb, L0);
+        int b1 = buf + 1; b1 = b1 >= STAGES ? b1 - STAGES : b1;   // buffer of K-step s+1
+        int b2 = b1 + 1; b2 = b2 >= STAGES ? b2 - STAGES : b2;   // 3 stages: buffer of K-step s+2 (2 stages: == buf)
+        read_frags(sb, 1, fa[1], fb[1]);
+        if constexpr (HAS2 && P2 > 0) {
+            mfma_half(fa[0], fb[0], IntC<P2>{}, s + 2, b2, L0);
             end_step();
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // the fragment reads first,
+            pin_loads_between_mfmas<FM * FN, P2>();                    // then MFMA groups with one LDS-DMA after each
         } else {
-            // one K-step of slack only: the loads must leave first (another workgroup on the CU covers their issue time)
-            stage(lks, nb);
-            half_step(sb, 0, IntC<0>{}, 0, 0, 0);
-            half_step(sb, 1, IntC<0>{}, 0, 0, 0);
+            mfma_half(fa[0], fb[0], IntC<0>{}, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+            pin_loads_between_mfmas<FM * FN, 0>();
         }
+        if (s + 1 >= nk) {  // last K-step: nothing to publish or prefetch
+            mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
+            return;
+        }
+        // K-step s+1 has landed when only K-step s+2's loads (all issued by now) are outstanding
+        if constexpr (HAS2 && STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        // This wave's reads of K-step s must be complete before the barrier (the buffer is refilled behind it).  Asking for the
+        // registers makes hipcc place that wait HERE, where nothing younger is outstanding; left alone it waits for them in front of
+        // the MFMAs below as lgkmcnt(0), which would also sit out the fragment reads issued just before -- the prefetch would be lost.
+#pragma unroll
+        for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(fa[1][j]));
+#pragma unroll
+        for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[1][i]));
+        __builtin_amdgcn_s_barrier();
+        if constexpr (HAS4 && STAGES == 2) stage(s + 2, buf);  // one K-step of slack only: the loads leave first
+        read_frags(smem + b1 * STAGE, 0, fa[0], fb[0]);
+        if constexpr (HAS4 && STAGES == 3) {
+            begin_step(s + 3);
+            mfma_half(fa[1], fb[1], IntC<P4>{}, s + 3, buf, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+            pin_loads_between_mfmas<FM * FN, P4>();
+        } else {
+            mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+            pin_loads_between_mfmas<FM * FN, 0>();
+        }
+    };
+
+    int buf = 0, s = 0;
+    // steady state: both load groups exist (3 stages: K-steps s+2 and s+3; 2 stages: K-step s+2)
+    for (; s + STAGES < nk; ++s) {
+        iteration(s, buf, IntC<1>{}, IntC<1>{});
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
-    // drain: the last STAGES-1 K-steps have nothing left to prefetch
-    for (int ks = nmain; ks < nk; ++ks) {
-        if (STAGES == 3 && ks + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const char* sb = smem + buf * STAGE;
-        half_step(sb, 0, IntC<0>{}, 0, 0, 0);
-        half_step(sb, 1, IntC<0>{}, 0, 0, 0);
+    if (STAGES == 3 && s + 2 < nk) {  // K-step s+2 is the last one: its second part still has to leave
+        iteration(s, buf, IntC<1>{}, IntC<0>{});
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        ++s;
+    }
+    for (; s < nk; ++s) {  // drain: nothing left to fetch
+        iteration(s, buf, IntC<0>{}, IntC<0>{});
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
 
