@@ -275,3 +275,26 @@ def test_dbnet_r50_halo_plane_head_entry(hip, monkeypatch, cfg):
 def test_macs_accounting(r18):
     eng, _ = r18
     assert eng.macs_per_frame == pytest.approx(34.91e9, rel=0.01)  # 69.8 GFLOP / frame
+
+
+def test_register_epilogue_bit_identical_to_lds_epilogue(hip, monkeypatch):
+    """conv_igemm.hip finishes plain NHWC layers straight from the accumulators (weight rows permuted so that a lane owns 8
+    consecutive channels).  Same operations in the same order as the LDS epilogue: every tap and the probability map must be
+    bit-identical with VTD_EPI_DIRECT=0, on the layer-by-layer graph (every conv flavour: stride 2, residual, 1x1, top-down add)."""
+    from vtd_amd.engine import DetectorEngine
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(99))
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VTD_EPI_DIRECT", mode)
+        monkeypatch.setenv("VTD_HALO_CONV", "0")   # every convolution on the implicit GEMM
+        eng = DetectorEngine("resnet18", sd, max_batch=3, options={"fuse_fpn_head": 0, "fuse_stem_pool": 0, "head_tail_kernel": 0})
+        try:
+            prob = eng.forward(x)["probability"].cpu().numpy()
+            taps = [eng.read_tap(n, 3) for n in ("c2", "c3", "c4", "c5", "p2")]
+        finally:
+            eng.close()
+        outs[mode] = (prob, taps)
+    for a, b, n in zip(outs["1"][1], outs["0"][1], ("c2", "c3", "c4", "c5", "p2")):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(outs["1"][0], outs["0"][0])

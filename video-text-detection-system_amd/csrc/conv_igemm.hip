@@ -74,6 +74,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Register epilogue (plain NHWC output, bias / residual / ReLU only): decided by the launcher, uniform over the grid
+    const bool direct = !CLASSED && BN != 256 && p.epi_direct != 0;
 
     // ---- loader state: each lane owns one 16-byte chunk slot of A_INST + B_INST rows
     const int lrow = lane >> 3;
@@ -106,7 +108,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     if constexpr (CLASSED) wbase += (int64_t)(cl_entry & 0xff) * p.cout_pad * p.K;
     const half_t* bptr[B_INST];
 #pragma unroll
-    for (int i = 0; i < B_INST; ++i) bptr[i] = wbase + (int64_t)(n0 + (i * NW + w) * 8 + lrow) * p.K + c_log * 8;
+    for (int i = 0; i < B_INST; ++i) {
+        int brow = (i * NW + w) * 8 + lrow;  // B-tile row in LDS = MFMA row (brow & 15) of fragment block (brow >> 4)
+        if (direct) {
+            // register epilogue: LDS row `brow` is fed with the weights of another channel of the same wave sub-tile, chosen so
+            // that the accumulators of a lane -- rows 4 fq .. 4 fq + 3 of every 16-row block -- are CONSECUTIVE channels:
+            // acc[i][.][e] of lane group fq = channel 32 (i >> 1) + 8 fq + 4 (i & 1) + e of the sub-tile
+            const int x = brow % TN, blk = x >> 4, r = x & 15;
+            brow = brow - x + 32 * (blk >> 1) + 8 * (r >> 2) + 4 * (blk & 1) + (r & 3);
+        }
+        bptr[i] = wbase + (int64_t)(n0 + brow) * p.K + c_log * 8;
+    }
 
     // K walk state (scalar): kb = element offset of the current K-step from the tap-(0,0) pixel
     int kb = 0, t_c = 0, t_s = 0;
@@ -182,6 +194,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // s + STAGES.  With 3 stages those loads are spread over the MFMAs of the two half-steps after the barrier and have until
     // B(s+3); with 2 stages they all leave right after the barrier and have one K-step, as before.
     auto read_frags = [&](const char* sb, int kk, half8 (&af)[FM], half8 (&bf)[FN]) {
+#ifdef VTD_CONV_EXPERIMENT
+        if (p.dbg == 6 && sb != smem) return;
+#endif
         const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
 #pragma unroll
         for (int j = 0; j < FM; ++j) af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
@@ -255,6 +270,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(fa[1][j]));
 #pragma unroll
         for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[1][i]));
+#ifdef VTD_CONV_EXPERIMENT
+        if (p.dbg != 4)
+#endif
         __builtin_amdgcn_s_barrier();
         if constexpr (HAS4 && STAGES == 2) stage(s + 2, buf);  // one K-step of slack only: the loads leave first
         read_frags(smem + b1 * STAGE, 0, fa[0], fb[0]);
@@ -286,6 +304,74 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
 
+    // ---- register epilogue.  The LDS round trip below (fp32 tile out, 8-channel rows back in, two workgroup barriers, a pixel
+    // table) was 20-37 % of these launches (tools/conv_experiment.sh, VTD_CONV_DEBUG=5).  With the weight rows permuted as above a
+    // lane already holds 8 consecutive channels of each of its FM pixels per pair of fragment blocks: (acc + bias) + residual, ReLU,
+    // one fp16 rounding -- the same operations in the same order as below, so both paths give identical bits -- and one 16-byte
+    // store; the four lane groups of a pixel write 64 contiguous bytes.  No barrier: a wave leaves as soon as its own MFMAs are done.
+    if constexpr (!CLASSED && BN != 256 && (FN % 2) == 0) {
+        if (direct) {
+            const int fq = lane >> 4;
+            int64_t o_off[FM], r_off[FM];
+            bool ok[FM];
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                int m = m0 + wm * TM + j * 16 + frow;
+                ok[j] = m < p.M;
+                m = ok[j] ? m : p.M - 1;
+                const int img = (int)(((uint64_t)(uint32_t)m * p.magic_howo) >> 40);
+                const int rem = m - img * howo;
+                const int oy = (int)(((uint64_t)(uint32_t)rem * p.magic_wo) >> 40), ox = rem - oy * p.wo;
+                o_off[j] = ((int64_t)(img * p.out_hp + oy + p.out_ring) * p.out_wp + ox + p.out_ring) * p.out_c;
+                r_off[j] = ((int64_t)(img * p.res_hp + (oy >> p.res_shift) + p.res_ring) * p.res_wp + (ox >> p.res_shift) + p.res_ring) * p.cout;
+            }
+            const bool has_res = (p.flags & EPI_RESIDUAL) != 0, relu = (p.flags & EPI_RELU) != 0;
+#pragma unroll
+            for (int k = 0; k < FN / 2; ++k) {
+                const int ch = n0 + wn * TN + 32 * k + 8 * fq;
+                if (ch >= p.cout) continue;  // cout % 8 == 0: a chunk is valid as a whole
+                half8 resv[FM];
+                if (has_res) {
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) resv[j] = *(const half8*)(p.res + r_off[j] + ch);
+                }
+                const floatx4 b0 = *(const floatx4*)(p.bias + ch), b1 = *(const floatx4*)(p.bias + ch + 4);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    floatx4 v0 = acc[2 * k][j] + b0, v1 = acc[2 * k + 1][j] + b1;
+                    half8 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a0 = v0[e], a1 = v1[e];
+                        if (has_res) { a0 += (float)resv[j][e]; a1 += (float)resv[j][4 + e]; }
+                        if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+                        hv[e] = (half_t)a0;
+                        hv[4 + e] = (half_t)a1;
+                    }
+#ifdef VTD_CONV_EXPERIMENT
+                    if (p.dbg == 7) { asm volatile("" ::"v"(hv)); continue; }  // everything but the stores
+#endif
+                    if (ok[j]) *(half8*)((half_t*)p.out + o_off[j] + ch) = hv;
+                }
+            }
+#ifdef VTD_CONV_EXPERIMENT
+            if (p.dbg == 9) wait_vmcnt<0>();  // does a wave that ends with stores in flight hold its slot anyway?
+#endif
+            return;
+        }
+    }
+
+#ifdef VTD_CONV_EXPERIMENT
+    if (p.dbg == 5) {  // no epilogue: keep the accumulators alive with one store per wave
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) ((float*)p.out)[0] = t;
+        return;
+    }
+#endif
     // ---- epilogue phase 1: accumulators -> fp32 tile in LDS (weights were the A operand: a lane holds 4
     //      consecutive channels (lane>>4)*4.. of pixel lane&15), plus the pixel coordinates of the tile rows
     __syncthreads();  // all waves are done with the staging buffers
@@ -530,6 +616,18 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
     if (!p.plist && (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw)))) return -1006;
     if (cfg < 0) cfg = vtd_conv_default_config(p);
     if (!vtd_conv_config_valid(p, cfg)) return -1007;
+    {   // register epilogue: plain NHWC fp16 output with bias / residual / ReLU only, and exact magic divisions for m -> (img, oy, ox)
+        const char* e = getenv("VTD_EPI_DIRECT");  // tests: 0 = the LDS epilogue everywhere (read per launch so a test can flip it)
+        const bool allow = !(e && e[0] == '0');
+        const uint64_t howo = (uint64_t)p.ho * (uint64_t)p.wo;
+        p.epi_direct = 0;
+        if (allow && !p.plist && !(p.flags & ~(EPI_RELU | EPI_RESIDUAL)) && !(p.cout & 7) && (uint64_t)p.M * howo < (1ull << 40) &&
+            (!(p.flags & EPI_RESIDUAL) || p.res)) {
+            p.epi_direct = 1;
+            p.magic_wo = ((1ull << 40) + p.wo - 1) / p.wo;
+            p.magic_howo = ((1ull << 40) + howo - 1) / howo;
+        }
+    }
     switch (cfg) {
         case 0: return launch_cfg<256, 128, 4, 2, 3>(p, stream);
         case 1: return launch_cfg<128, 128, 2, 2, 2>(p, stream);

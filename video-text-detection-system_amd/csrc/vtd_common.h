@@ -60,8 +60,10 @@ struct ConvParams {
     int res_hp, res_wp, res_ring, res_shift;
     int ps_cout;           // pixel-shuffle: channels per (ky,kx) block
     int flags;
-    int dbg;               // timing experiments only (VTD_CONV_DEBUG): 1 = A gather pinned to tap 0, 2 = no A loads, 3 = no loads
+    int dbg;               // timing experiments only (VTD_CONV_DEBUG): 1 = A gather pinned to tap 0, 2 = no A loads, 3 = no loads, 4 = no loop barrier, 5 = no epilogue, 6 = no fragment reads after the first
     int ldc;               // EPI_OUT_F32 row stride
+    int epi_direct;        // set by vtd_launch_conv: epilogue straight from the accumulators (conv_igemm.hip)
+    uint64_t magic_wo, magic_howo;  // ceil(2^40 / wo), ceil(2^40 / (ho * wo)) for it
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
     const int* tile_combo;   // per tile in execution order: weight class | pixel-list chunk << 8
