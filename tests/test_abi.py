@@ -39,3 +39,36 @@ def test_error_strings_and_argument_validation_without_device():
     assert lib.vtd_detector_set_tensor(h, b"backbone.1.num_batches_tracked", buf, 1) == 0
     assert lib.vtd_detector_forward(h, 1, buf, None, None) == -1104  # not finalized
     lib.vtd_detector_destroy(h)
+
+
+def test_head_entry_half_halo_schedule_is_hazard_free_and_complete():
+    """head_entry_half.hip walks the composed head entry's K in half-steps on two 32-channel half halos that are refilled while
+    the other half is multiplied.  The host-built schedule (no GPU needed) must (a) pass its own replay -- no half halo read
+    before two steps after its fetch, none refilled while a later half-step still wants its content --, (b) visit every
+    (K-step, channel half) of the head_entry_halo256 step table exactly once with the right weight columns, and (c) keep the
+    half halos alternating.  Internal C++ entry points, looked up by their mangled names."""
+    import numpy as np
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    steps_fn = getattr(lib, "_Z25vtd_head_entry_halo_stepsiiiPi")
+    sched_fn = getattr(lib, "_Z28vtd_head_entry_half_schedulePKiiPi")
+    for nch1 in (1, 4):                      # C2 of 64 (ResNet-18) / 256 (ResNet-50) channels
+        ns = 25 * nch1 + 36
+        for cls in range(4):
+            st = (ctypes.c_int * (ns * 2))()
+            assert steps_fn(cls >> 1, cls & 1, nch1, st) == ns
+            out = (ctypes.c_int * (ns * 4))()
+            assert sched_fn(st, ns, out) == 0
+            steps = np.array(st).reshape(ns, 2)
+            o = np.array(out).reshape(ns, 4)
+            want = sorted((int(k) + 32 * h, int(t) & 0xff, (int(t) >> 16) & 3) for k, t in steps for h in (0, 1))
+            got = sorted((int(o[s, 2] >> (16 * k)) & 0xffff, int(o[s, k]) & 0xff, (int(o[s, k]) >> 8) & 3) for s in range(ns) for k in (0, 1))
+            assert got == want
+            # column offset parity tells the channel half: it must match the half-halo bit of the descriptor
+            for s in range(ns):
+                for k in (0, 1):
+                    assert ((int(o[s, 2]) >> (16 * k)) & 0xffff) // 32 % 2 == (int(o[s, k]) >> 10) & 1
+            fetches = [(s, (int(o[s, 3]) >> 7) & 1) for s in range(ns) if (int(o[s, 3]) >> 15) & 1]
+            groups = int((steps[:, 1] >> 8 & 1).sum())
+            assert len(fetches) == 2 * (groups - 1)
+            assert [h for _, h in fetches] == [0, 1] * (groups - 1)
+            assert all(b[0] - a[0] >= 2 for a, b in zip(fetches, fetches[1:]))   # never two fetches at consecutive step tops

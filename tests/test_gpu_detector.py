@@ -129,7 +129,7 @@ def test_dbnet_fused_stem_pool(r18, r18_fused):
         eng_f.read_tap("stem", 1)  # never materialised
 
 
-@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 102, 103, 105])
+@pytest.mark.parametrize("cfg", [8, 9, 10, 11, 102, 103, 105, 107])
 def test_composed_head_entry_every_tile_configuration(hip, monkeypatch, cfg):
     """The composed conv on each of its tile configurations (128- and 256-row pixel-list tiles, 2 / 3 LDS stages): same
     probabilities as the fp32 oracle, borders included (the per-class padding rows of the two list cuts differ)."""
@@ -148,7 +148,7 @@ def test_composed_head_entry_every_tile_configuration(hip, monkeypatch, cfg):
     finally:
         eng.close()
     want = {8: "128,64,s2,classed", 9: "128,64,s3,classed", 10: "256,64,s2,classed", 11: "256,64,s3,classed",
-            102: "head_entry_halo M", 103: "head_entry_halo256", 105: "head_entry_pair"}[cfg]  # 102 / 103: interior classes on the halo-plane kernels
+            102: "head_entry_halo M", 103: "head_entry_halo256", 105: "head_entry_pair", 107: "head_entry_half"}[cfg]  # 102 / 103: interior classes on the halo-plane kernels
     # (8x16 / 16x16 pixel blocks), border classes on 128-row gathered tiles
     assert any(want in n for n in names), names
     assert _rel(h1, h1_ref) < 1.5e-2

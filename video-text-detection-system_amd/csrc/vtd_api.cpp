@@ -27,6 +27,8 @@ void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
 int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream);
+int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out);
+int vtd_launch_head_entry_half(const ConvParams& c, const int* sched_dev, int nsteps, hipStream_t stream);
 int vtd_head_entry_pair_tables(int py, int px, int c2ch, int* half_steps, int* plan);
 int vtd_launch_head_entry_pair(const ConvParams& c, const int* half_steps_dev, const int* plan_dev, int nh, hipStream_t stream);
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
@@ -113,6 +115,7 @@ struct ConvOp {
     int tiles_border = 0;
     const int* he_steps = nullptr;  // step tables of the four interior classes
     int he_nsteps = 0;
+    const int* hh_sched = nullptr;  // head_entry_half.hip: half-step schedules of the four interior classes
     const int* hp_half_steps = nullptr;  // head_entry_pair.hip: half-step tables and halo prefetch plans of the four interior classes
     const int* hp_plan = nullptr;
     int hp_nh = 0;
@@ -166,6 +169,7 @@ static const int kHalo64Cfg = 104;  // second-generation halo kernel: 64 output 
 static const int kHeadEntryHalo256Cfg = 103;  // same, 16x16 pixel blocks with 64x64 register tiles (hand-pipelined)
 static const int kHeadEntryPairCfg = 105;  // two 16x16 blocks per workgroup on one weight ring, 32-channel halos prefetched two groups ahead
 static const int kPointwiseCfg = 106;  // streaming 1x1 convolution 128 -> 256 with the top-down add (pointwise.hip): the C3 lateral
+static const int kHeadEntryHalfCfg = 107;  // 16x16 blocks on 32-channel half halos fetched two K-steps ahead (head_entry_half.hip): no exposed halo switch
 static const int kHeadEntryHaloCfg = 102;  // composed head entry: interior classes on head_entry_halo.hip, border classes on cfg 8
 static bool halo_enabled() {
     const char* e = std::getenv("VTD_HALO_CONV");
@@ -179,6 +183,10 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     if (cfg == kHeadEntryPairCfg) {
         if (!c.hp_half_steps || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_pair(p, c.hp_half_steps, c.hp_plan, c.hp_nh, s);
+    }
+    if (cfg == kHeadEntryHalfCfg) {
+        if (!c.hh_sched || !c.tile_combo_border) return ERR_GEOMETRY;
+        return vtd_launch_head_entry_half(p, c.hh_sched, c.he_nsteps, s);
     }
     if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) {  // interior classes only; border tiles = the next graph slot
         if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
@@ -218,6 +226,7 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     if (p.plist) {  // tests: pin the composed conv to one tile configuration (8..11)
         const char* fc = std::getenv("VTD_FORCE_CLASSED_CFG");
         if (fc && (vtd_conv_config_valid(p, std::atoi(fc)) || ((std::atoi(fc) == kHeadEntryHaloCfg || std::atoi(fc) == kHeadEntryHalo256Cfg) && c.he_steps) ||
+                   (std::atoi(fc) == kHeadEntryHalfCfg && c.hh_sched) ||
                    (std::atoi(fc) == kHeadEntryPairCfg && c.hp_half_steps))) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
@@ -238,9 +247,10 @@ static int autotune_conv(const ConvOp& c, int n, hipStream_t s, int* best_cfg) {
     }
     if (!rc && p.plist && c.he_steps && halo_enabled()) {  // composed head entry: halo-plane kernels + border tiles
         const float best_gathered = best;
-        for (int variant = 0; variant < 3 && !rc; ++variant) {
+        for (int variant = 0; variant < 4 && !rc; ++variant) {
             if (variant == 2 && !c.hp_half_steps) continue;
-            const int vcfg = variant == 2 ? kHeadEntryPairCfg : variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
+            if (variant == 3 && !c.hh_sched) continue;
+            const int vcfg = variant == 3 ? kHeadEntryHalfCfg : variant == 2 ? kHeadEntryPairCfg : variant ? kHeadEntryHalo256Cfg : kHeadEntryHaloCfg;
             auto both = [&]() { int r = launch_conv_op(c, n, s, vcfg); return r ? r : launch_border_tiles(c, n, s); };
             if ((rc = both())) break;
             float ms = 1e30f;
@@ -389,6 +399,7 @@ static bool config_valid_for(const ConvOp& c, int n, int cfg) {
     ConvParams p;
     fill_conv_params(c, n, p);
     if (cfg == kHeadEntryPairCfg) return p.plist && c.hp_half_steps && c.tile_combo_border;
+    if (cfg == kHeadEntryHalfCfg) return p.plist && c.hh_sched && c.tile_combo_border;
     if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) return p.plist && c.he_steps && c.tile_combo_border;
     if (cfg == kHaloCfg || cfg == kHaloC64Cfg || cfg == kHalo64Cfg) {
         int bn = 0, tw = 0;
@@ -865,6 +876,17 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
         if ((rc = upload(d->arena, steps.data(), steps.size() * sizeof(int), &st))) return rc;
         if ((rc = upload(d->arena, border.data(), border.size() * sizeof(int), &bd))) return rc;
         op.he_steps = (const int*)st; op.he_nsteps = nsteps;
+        if (25 * c2.c + 9 * 256 <= 0xffff) {  // half-halo kernel: schedules derived from the same step tables (16-bit weight column offsets)
+            std::vector<int> sched((size_t)4 * nsteps * 4);
+            bool ok = true;
+            for (int q = 0; q < 4 && ok; ++q)
+                ok = vtd_head_entry_half_schedule(&steps[(size_t)q * nsteps * 2], nsteps, &sched[(size_t)q * nsteps * 4]) == 0;
+            void* sd = nullptr;
+            if (ok) {
+                if ((rc = upload(d->arena, sched.data(), sched.size() * sizeof(int), &sd))) return rc;
+                op.hh_sched = (const int*)sd;
+            }
+        }
         op.tile_combo_border = (const int*)bd; op.tiles_border = (int)border.size();
         {   // pair kernel (head_entry_pair.hip): half-step tables + halo prefetch plans; only where its LDS budget holds (C2 of 64 channels)
             const int nh = 25 * (c2.c / 32) + 72;
@@ -1305,7 +1327,7 @@ int vtd_detector_forward(vtd_detector* d, int n, float* prob_dev, float* thresh_
         const Op& o = d->ops[oi];
         int rc = 0;
         if (o.final_slot == 1 && !thresh_dev) continue;
-        if (o.kind == Op::BORDER && (oi == 0 || (cfgs[oi - 1] != kHeadEntryHaloCfg && cfgs[oi - 1] != kHeadEntryHalo256Cfg && cfgs[oi - 1] != kHeadEntryPairCfg)))
+        if (o.kind == Op::BORDER && (oi == 0 || (cfgs[oi - 1] != kHeadEntryHaloCfg && cfgs[oi - 1] != kHeadEntryHalo256Cfg && cfgs[oi - 1] != kHeadEntryPairCfg && cfgs[oi - 1] != kHeadEntryHalfCfg)))
             continue;  // the gathered kernel did every class
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool prof = d->profiling && (d->prof_only < 0 || d->prof_only == (int)oi);
@@ -1387,6 +1409,9 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
         if (cfg == kHeadEntryPairCfg)
             std::snprintf(name, name_cap, "head_entry_pair M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
+                          "next slot)", c.ho * c.wo, c.cout, c.K);
+        else if (cfg == kHeadEntryHalfCfg)
+            std::snprintf(name, name_cap, "head_entry_half M/img=%d N=%d K=%d (lateral+smooth+head conv composed, half halos two steps ahead; border classes in the "
                           "next slot)", c.ho * c.wo, c.cout, c.K);
         else if (cfg == kHeadEntryHalo256Cfg)
             std::snprintf(name, name_cap, "head_entry_halo256 M/img=%d N=%d K=%d (lateral+smooth+head conv composed; border classes in the "
