@@ -298,3 +298,32 @@ def test_register_epilogue_bit_identical_to_lds_epilogue(hip, monkeypatch):
     for a, b, n in zip(outs["1"][1], outs["0"][1], ("c2", "c3", "c4", "c5", "p2")):
         assert np.array_equal(a, b), n
     assert np.array_equal(outs["1"][0], outs["0"][0])
+
+
+@pytest.mark.parametrize("cfg", [12, 13, 0, 5])
+def test_implicit_gemm_tile_heights_bit_identical(hip, monkeypatch, cfg):
+    """Tile configurations 12 / 13 (208- and 272-row tiles, wave rows of 7 + 6 / 9 + 8 fragments, spare LDS-DMA instructions
+    re-fetching the last piece) forced wherever they are valid, on the layer-by-layer graph at a batch whose row counts are not
+    multiples of the tile height: every tap and the probability map bit-identical to the shipped selection (a tile shape changes
+    which workgroup computes an output, never the order of its K sum).  0 and 5 (256 x 128, 128 x 64) as controls."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    x = torch.randn(3, 3, 640, 640, generator=torch.Generator().manual_seed(123))
+    outs = {}
+    for mode in (str(cfg), None):
+        if mode: monkeypatch.setenv("VTD_FORCE_CONV_CFG", mode)
+        else: monkeypatch.delenv("VTD_FORCE_CONV_CFG", raising=False)
+        monkeypatch.setenv("VTD_HALO_CONV", "0")
+        eng = DetectorEngine("resnet18", sd, max_batch=3, options={"fuse_fpn_head": 0, "fuse_stem_pool": 0, "head_tail_kernel": 0})
+        try:
+            prob = eng.forward(x)["probability"].cpu().numpy()
+            taps = [eng.read_tap(n, 3) for n in ("c2", "c3", "c4", "c5", "p2")]
+            names = [r[0] for r in detector_profile(eng)]
+        finally:
+            eng.close()
+        outs[mode] = (prob, taps, names)
+    want = {12: "208,128,s3", 13: "272,128,s3", 0: "256,128,s3", 5: "128,64,s2"}[cfg]
+    assert sum(want in n for n in outs[str(cfg)][2]) >= 8, outs[str(cfg)][2]
+    for a, b, n in zip(outs[str(cfg)][1], outs[None][1], ("c2", "c3", "c4", "c5", "p2")):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(outs[str(cfg)][0], outs[None][0])

@@ -51,14 +51,22 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
+    // Tile heights that are not a multiple of 8 * NW or of 16 * WM (208, 272: chosen so that a layer's tile count fills whole rounds
+    // of the 256 CUs, see vtd_launch_conv) round the loader up to whole LDS-DMA instructions per wave (every wave issues the same
+    // number: the counted waits depend on it; the spare ones fetch the tile's last 8 rows again, same bytes to the same LDS rows)
+    // and give the LAST wave row fewer fragments (UNEVEN).
+    constexpr int A_INST = (BM + 8 * NW - 1) / (8 * NW);  // global_load_lds instructions per wave per K-step for the A tile
+    constexpr int A_PIECES = BM / 8;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INST = BM / (8 * NW);  // global_load_lds instructions per wave per K-step for the A tile
     constexpr int B_INST = BN / (8 * NW);
     constexpr int LOADS = A_INST + B_INST;
-    constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int FM = (BM / 16 + WM - 1) / WM, TM = FM * 16, TN = BN / WN;  // fragments per wave row (the last one may have fewer)
+    constexpr int FN = TN / 16;
+    constexpr bool UNEVEN = (BM / 16) % WM != 0;
+    static_assert(BM % 16 == 0 && (BM / 16 - (WM - 1) * FM) >= 1, "tile height");
+    static_assert(!UNEVEN || (!CLASSED && BN != 256), "uneven wave rows finish from registers only");
     static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8), "tile/wave shape");
     static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
     constexpr int EPI_ROW = BN * 4 + 16;  // fp32 tile row stride (bytes), padded by one 16-byte slot
@@ -96,12 +104,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             aptr[i] = p.in + ((int64_t)(cl_img * p.in_hp + oy + p.in_y0) * p.in_wp + ox + p.in_x0) * p.in_c + c_off;
             aptr2[i] = p.in2 + ((int64_t)(cl_img * p.in2_hp + (oy >> 1) + p.in2_ring - 1) * p.in2_wp + (ox >> 1) + p.in2_ring - 1) * p.in2_c + c_off;
         } else {
-            int m = m0 + (i * NW + w) * 8 + lrow;
+            int piece = i * NW + w;
+            piece = piece < A_PIECES ? piece : A_PIECES - 1;  // spare instruction of a tile height that is not a multiple of 8 * NW
+            // (its swizzle key must be the one of the LDS rows it lands in: piece parity, not wave parity)
+            const int cl_i = (lane & 7) ^ (((piece & 1) << 2) | (lane >> 4));
+            const int c_off_i = (cl_i >> 2) * p.k_hi_step + (cl_i & 3) * 8;
+            int m = m0 + piece * 8 + lrow;
             m = m < p.M ? m : p.M - 1;
             const int img = m / howo;
             const int rem = m - img * howo;
             const int oy = rem / p.wo, ox = rem - oy * p.wo;
-            aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off;
+            aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off_i;
         }
     }
     const half_t* wbase = p.wgt;
@@ -137,7 +150,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #else
             const half_t* src = (second ? aptr2[CLASSED ? j : 0] : aptr[j]) + kb;
 #endif
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + (j * NW + w) * 1024), 16, 0, 0);
+            const int piece = j * NW + w < A_PIECES ? j * NW + w : A_PIECES - 1;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)src, (VTD_AS3 void*)(abase + piece * 1024), 16, 0, 0);
         } else {
             const int i = j - A_INST;
             __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bptr[i] + ks * 64), (VTD_AS3 void*)(abase + A_BYTES + (i * NW + w) * 1024), 16, 0, 0);
@@ -172,6 +186,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int frow = lane & 15;
     const int swz = (lane >> 1) & 7;  // (row>>1)&7 for every fragment row this lane reads
     const int a_lane_off = (wm * TM + frow) * 128;
+    // UNEVEN: the last wave row owns FM - 1 fragments (static_assert below): only fragment FM - 1 is conditional, on one wave-uniform flag
+    constexpr int LAST_FM = BM / 16 - (WM - 1) * FM;
+    static_assert(!UNEVEN || LAST_FM == FM - 1, "uneven wave rows differ by exactly one fragment");
+    const bool full_row = !UNEVEN || wm != WM - 1;
     const int b_lane_off = A_BYTES + (wn * TN + frow) * 128;
 
     floatx4 acc[FN][FM];
@@ -199,7 +217,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #endif
         const int phys = (((lane >> 4) + 4 * kk) ^ swz) * 16;
 #pragma unroll
-        for (int j = 0; j < FM; ++j) af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
+        for (int j = 0; j < FM; ++j) {
+            if (UNEVEN && j == FM - 1 && !full_row) { af[j] = af[0]; continue; }  // (keeps the register defined; its MFMAs are skipped)
+            af[j] = *(const half8*)(sb + a_lane_off + j * 2048 + phys);
+        }
 #pragma unroll
         for (int i = 0; i < FN; ++i) bf[i] = *(const half8*)(sb + b_lane_off + i * 2048 + phys);
     };
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
+                if (!UNEVEN || j < FM - 1 || full_row) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i], af[j], acc[i][j], 0, 0, 0);
                 ++q;
                 if (issued < nload && q >= (issued + 1) * NM / (nload + 1)) {
                     issue_load(j0 + issued, lks, lbuf);
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 int m = m0 + wm * TM + j * 16 + frow;
-                ok[j] = m < p.M;
+                ok[j] = m < p.M && (!UNEVEN || j < FM - 1 || full_row);
                 m = ok[j] ? m : p.M - 1;
                 const int img = (int)(((uint64_t)(uint32_t)m * p.magic_howo) >> 40);
                 const int rem = m - img * howo;
@@ -361,6 +382,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         }
     }
 
+    if constexpr (UNEVEN) return;  // (unreachable: the launcher admits these tile heights only with the register epilogue)
 #ifdef VTD_CONV_EXPERIMENT
     if (p.dbg == 5) {  // no epilogue: keep the accumulators alive with one store per wave
         float t = 0.f;
@@ -548,7 +570,8 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;  // (classed: vtd_launch_conv set M for this tile height)
     const int tiles_n = p.cout_pad / BN;
     constexpr int stage_bytes = STAGES * (BM + BN) * 128;
-    constexpr int epi_bytes = BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
+    constexpr bool uneven = (BM / 16) % WM != 0;  // register epilogue only: no fp32 staging tile
+    constexpr int epi_bytes = uneven ? 0 : BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -576,7 +599,17 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //   7   64x256    4     2        80 KB   2      only for the fused DB-head tail (EPI_HEAD_FINAL needs all 256 columns)
 //   8/9   128x64  4     2/3               only for the classed dual-source op (pixel-list tiles of 128 rows)
 //   10/11 256x64  4     2/3               same op, pixel lists cut into 256-row tiles: 17 % fewer LDS-DMA pieces per FLOP
-int vtd_conv_num_configs() { return 12; }
+//   12  208x128   8 (2x4) 3     126 KB   1      tile heights that fill whole rounds of the 256 CUs where 256 rows do not: 51 200 rows
+//   13  272x128   8 (2x4) 3     150 KB   1      x 256 channels = 494 tiles of 208 (two rounds at 0.81 of the 256-row tile's time each)
+//                                               instead of 400 of 256 (two rounds for 1.56); 69 632 rows = exactly 256 tiles of 272 per
+//                                               128 channels.  Wave rows of 7 + 6 / 9 + 8 fragments; register epilogue only
+int vtd_conv_num_configs() { return 14; }
+
+// plain NHWC fp16 output with bias / residual / ReLU only: what the register epilogue (and so configurations 12 / 13) can finish
+static bool epi_direct_eligible(const ConvParams& p) {
+    const uint64_t howo = (uint64_t)p.ho * (uint64_t)p.wo;
+    return !p.plist && !(p.flags & ~(EPI_RELU | EPI_RESIDUAL)) && !(p.cout & 7) && (uint64_t)p.M * howo < (1ull << 40) && (!(p.flags & EPI_RESIDUAL) || p.res);
+}
 
 bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
@@ -584,6 +617,10 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     switch (cfg) {
         case 0: case 1: case 2: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
+        case 12: case 13: {
+            const char* e = getenv("VTD_EPI_DIRECT");
+            return p.cout_pad % 128 == 0 && epi_direct_eligible(p) && !(e && e[0] == '0');
+        }
         default: return false;
     }
 }
@@ -621,8 +658,7 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         const bool allow = !(e && e[0] == '0');
         const uint64_t howo = (uint64_t)p.ho * (uint64_t)p.wo;
         p.epi_direct = 0;
-        if (allow && !p.plist && !(p.flags & ~(EPI_RELU | EPI_RESIDUAL)) && !(p.cout & 7) && (uint64_t)p.M * howo < (1ull << 40) &&
-            (!(p.flags & EPI_RESIDUAL) || p.res)) {
+        if (allow && epi_direct_eligible(p)) {
             p.epi_direct = 1;
             p.magic_wo = ((1ull << 40) + p.wo - 1) / p.wo;
             p.magic_howo = ((1ull << 40) + howo - 1) / howo;
@@ -639,6 +675,8 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         case 7: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
+        case 12: return launch_cfg<208, 128, 2, 4, 3>(p, stream);
+        case 13: return launch_cfg<272, 128, 2, 4, 3>(p, stream);
         default: {
             // 256-row classed tiles: same images, the other cut of the pixel lists
             const int n_img = p.M / (p.tiles_per_img * 128);

@@ -176,6 +176,27 @@ static bool halo_enabled() {
     return !(e && e[0] == '0');
 }
 
+// Configurations 0 / 12 / 13 are one kernel family (8 waves, 128 channels wide, 3 stages) at tile heights 256 / 208 / 272.  Which
+// height is cheapest depends on how the launch's tile count falls on the 256 CUs (one workgroup each), i.e. on the ACTUAL row count,
+// which a per-bucket table cannot know (272 crops and 512 crops share a bucket): rounds x time per tile.  Time per tile = height /
+// relative MFMA efficiency of the wave layout, measured on layer 2-4 and the CRNN (tools/gpu_tiles.sh): 4 x 2 waves of 64 x 64
+// (256 rows) 1.0, 2 x 4 waves of 9+8 fragments x 32 (272 rows) 0.92, 7+6 x 32 (208 rows) 0.80.  A pure function of the shape, and
+// tile height never changes a bit of the result (tests/test_gpu_detector.py: test_implicit_gemm_tile_heights_bit_identical).
+static int pick_tile_height(const ConvParams& p, int table_cfg) {
+    if (const char* e = std::getenv("VTD_TILE_HEIGHT_MODEL"); e && e[0] == '0') return table_cfg;
+    if (std::getenv("VTD_FORCE_CONV_CFG")) return table_cfg;  // tests pin one configuration
+    static const struct { int cfg, bm; double eff; } cand[3] = {{0, 256, 1.0}, {13, 272, 0.92}, {12, 208, 0.80}};
+    int best = table_cfg;
+    double best_cost = 0.0;
+    for (const auto& k : cand) {
+        if (!vtd_conv_config_valid(p, k.cfg)) continue;
+        const int64_t tiles = (int64_t)((p.M + k.bm - 1) / k.bm) * (p.cout_pad / 128);
+        const double cost = (double)((tiles + 255) / 256) * k.bm / k.eff;
+        if (best_cost == 0.0 || cost < best_cost * 0.97) { best_cost = cost; best = k.cfg; }  // 3 % hysteresis in favour of the earlier candidate
+    }
+    return best;
+}
+
 static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, float* prob_out = nullptr) {
     ConvParams p;
     fill_conv_params(c, n, p);
@@ -198,6 +219,7 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
         return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : cfg == kHalo64Cfg ? 2 : bn, tw, s);
     }
     if (cfg == kPointwiseCfg) return vtd_launch_pointwise128(p, s);
+    if (!c.plist && (cfg == 0 || cfg == 12 || cfg == 13)) cfg = pick_tile_height(p, cfg);
     return vtd_launch_conv(p, cfg, s);
 }
 
@@ -417,6 +439,10 @@ static int choose_config(ModelBase* m, const ConvOp& c, int n, hipStream_t s, in
     auto it = m->tuning.find(key);
     // test switches that pin a kernel variant (VTD_FORCE_CLASSED_CFG, VTD_FORCE_HALO) are honoured by the contest: they outrank the table
     const bool forced = std::getenv("VTD_FORCE_CLASSED_CFG") || std::getenv("VTD_FORCE_HALO");
+    if (const char* fc = std::getenv("VTD_FORCE_CONV_CFG"); fc && !c.plist && config_valid_for(c, n, std::atoi(fc))) {
+        *cfg = std::atoi(fc);  // tests: one implicit-GEMM tile configuration wherever it is valid, every other slot as usual
+        return 0;
+    }
     if (const char* fp = std::getenv("VTD_FORCE_POINTWISE"); fp && fp[0] == '1' && config_valid_for(c, n, kPointwiseCfg)) {
         *cfg = kPointwiseCfg;  // tests: the streaming 1x1 kernel wherever it applies, every other slot as usual
         return 0;
@@ -1404,7 +1430,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     if (o.kind == Op::CONV) {
         const ConvOp& c = o.conv;
         static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3",
-                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed"};
+                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed", "208,128,s3", "272,128,s3"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
         if (cfg == kHeadEntryPairCfg)
@@ -1425,7 +1451,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
             std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : cfg == kHalo64Cfg ? "64" : "",
                           c.ho * c.wo, c.cout, c.K);
         else
-            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 12) ? kTile[cfg] : "default",
+            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 14) ? kTile[cfg] : "default",
                           c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
