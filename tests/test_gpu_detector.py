@@ -327,3 +327,28 @@ def test_implicit_gemm_tile_heights_bit_identical(hip, monkeypatch, cfg):
     for a, b, n in zip(outs[str(cfg)][1], outs[None][1], ("c2", "c3", "c4", "c5", "p2")):
         assert np.array_equal(a, b), n
     assert np.array_equal(outs[str(cfg)][0], outs[None][0])
+
+
+def test_layer1_two_group_kernel_bit_identical(hip, monkeypatch):
+    """conv3x3_c64_duo_kernel (two wave groups of one workgroup alternating between multiplying and fetching / finishing) against
+    the one-group persistent kernel it replaces: same taps in the same order, so every layer-1 tap (c2) and the probability map
+    must be bit-identical, at a batch with an odd number of pixel blocks per workgroup (uneven last phase) and at batch 1."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
+    for n in (3, 1):
+        x = torch.randn(n, 3, 640, 640, generator=torch.Generator().manual_seed(200 + n))
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("VTD_C64_DUO", mode)
+            monkeypatch.setenv("VTD_FORCE_HALO", "2")   # the persistent 64 -> 64 kernel on all of layer 1
+            eng = DetectorEngine("resnet18", sd, max_batch=3, options={"fuse_fpn_head": 0})
+            try:
+                prob = eng.forward(x)["probability"].cpu().numpy()
+                c2 = eng.read_tap("c2", n)
+                names = [r[0] for r in detector_profile(eng)]
+            finally:
+                eng.close()
+            assert sum("c64_persistent" in nm for nm in names) == 4
+            outs[mode] = (prob, c2)
+        assert np.array_equal(outs["1"][1], outs["0"][1])
+        assert np.array_equal(outs["1"][0], outs["0"][0])

@@ -590,10 +590,169 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_persistent_kernel(const Ha
     hl_wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is handed on
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same convolution with TWO wave groups per workgroup taking turns (8 waves, one workgroup per CU, weights shared).
+// Stamps of the kernel above (VTD_HALO_STAMPS, per 16 x 16 pixel block): 12.5 k cycles of which the barrier-free K loop is 6.7 k
+// (4.6 k of MFMA issue); the other 5.8 k -- LDS-DMA issue for the next halo (one wave per SIMD: nobody covers the ~150 cycles a
+// wave is held per instruction), the residual round trip, the epilogue -- leave the matrix pipe idle.  Here group A (waves 0-3)
+// multiplies its block while group B (waves 4-7, the second wave on every SIMD) finishes the previous block of its own, fetches
+// its next halo and waits for it; one workgroup barrier, then they swap.  A group's halo buffer is single (it is refilled in the
+// group's own service phase, after its K loop), so LDS is the same 154 KB; accumulators and residual stay in registers across
+// the barrier.  No counted waits anywhere: a service phase ends with vmcnt(0), a compute phase issues nothing but the residual
+// reads.  Arithmetic per output is identical to the kernel above (same taps, same order): bit-identical maps.
+template <int TW, bool RELU, bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_c64_duo_kernel(const HaloParams p) {
+    constexpr int TH = 256 / TW, HWD = TW + 2, HROWS = (TH + 2) * HWD, HPIECES = (HROWS + 7) / 8, HBYTES = HPIECES * 1024;
+    constexpr int HPW = (HPIECES + 3) / 4;  // halo pieces per wave of a group
+    constexpr int WBYTES = 9 * 64 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wl = smem;                       // [9 taps][64 cout][128 B], 16-byte chunks swizzled by (cout >> 1) & 7
+    char* const hbuf = smem + WBYTES;            // one halo buffer per group (+ 1 KB landing pad for the padding loads)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wv >> 2, w = wv & 3;           // group, wave within the group
+    const int lrow = lane >> 3, fr = lane & 15, fq = lane >> 4;
+    const int tiles_per_img = p.tiles_x * p.tiles_y, total = p.n * tiles_per_img;
+
+    // ---- weights: 72 one-KB pieces, 9 per wave, once (row permutation as in the kernel above)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int piece = wv + 8 * k, tap = piece >> 3, row = (piece & 7) * 8 + lrow;
+        const int c_log = (lane & 7) ^ ((row >> 1) & 7);
+        const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);
+        __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.wgt + cout * 576 + tap * 64 + c_log * 8),
+                                         (VTD_AS3 void*)(wl + piece * 1024), 16, 0, 0);
+    }
+    // (register budget: two waves per SIMD = 256 registers; the bias lives in LDS, per-block addresses are recomputed per block)
+    float* const bias_lds = (float*)(smem + WBYTES + 2 * HBYTES + 1024);
+    if (tid < 64) bias_lds[tid] = p.bias[tid];
+
+    auto tile_coords = [&](int t, int& img, int& y0, int& x0) {
+        img = t / tiles_per_img;
+        const int r = t - img * tiles_per_img, ty = r / p.tiles_x;
+        y0 = ty * TH;
+        x0 = (r - ty * p.tiles_x) * TW;
+    };
+    auto issue_halo = [&](int t) {
+        int img, y0, x0;
+        tile_coords(t, img, y0, x0);
+        const half_t* base = p.in + ((int64_t)(img * p.in_hp + y0 - 1 + p.in_ring) * p.in_wp + x0 - 1 + p.in_ring) * 64;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const int piece = w + 4 * k;
+            int row = piece * 8 + lrow;
+            row = row < HROWS ? row : HROWS - 1;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            const int hrel = (hy * p.in_wp + hx) * 64 + ((lane & 7) ^ (hx & 6)) * 8;  // chunks keyed by the halo COLUMN: see load_frags
+            const int hdst = piece < HPIECES ? WBYTES + g * HBYTES + piece * 1024 : WBYTES + 2 * HBYTES;
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(base + hrel), (VTD_AS3 void*)(smem + hdst), 16, 0, 0);
+        }
+    };
+    // pixel m = w * 64 + j * 16 + fr of the block: row m / TW, column m % TW (TW is 16 or 32: shifts)
+    auto px_row = [&](int j) { return (w * 64 + j * 16 + fr) / TW; };
+    auto px_col = [&](int j) { return (w * 64 + j * 16 + fr) % TW; };
+    // A lane's four pixels share their column modulo 16 (TW = 16: rows w*4 + j; TW = 32: rows w*2 + (j >> 1), columns fr + 16 (j & 1)), and
+    // the halo's 16-byte chunks are XOR-ed with (halo column & 6): one address per half K-step, four reads at compile-time offsets
+    // (the kernel above keys by the halo ROW: six address instructions per read; here that cost the registers two waves per SIMD lack)
+    const int a_lane_off = (px_row(0) * HWD + px_col(0)) * 128;
+    const int b_lane_off = fr * 128;
+    const int bswz = (fr >> 1) & 7;
+    const char* const hb = hbuf + g * HBYTES;
+
+    // this workgroup's blocks q_j = blockIdx + j * grid; group g takes j = g, g + 2, ...
+    const int nq = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nmine = (nq - g + 1) >> 1;
+    const int phases = 2 * ((nq + 1) >> 1) > 2 * (nq >> 1) + 1 ? 2 * ((nq + 1) >> 1) : 2 * (nq >> 1) + 1;
+    auto block_of = [&](int i) { return (int)blockIdx.x + (2 * i + g) * (int)gridDim.x; };
+
+    if (nmine > 0) issue_halo(block_of(0));
+    hl_wait_vmcnt<0>();               // weights (every wave's share) and the first halo
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the bias is in LDS
+    __builtin_amdgcn_s_barrier();
+
+    floatx4 acc[4][4];
+    half8 rv[4][2];
+    for (int phase = 0; phase < phases; ++phase) {
+        if ((phase & 1) == g) {
+            // ---- compute phase: K loop of my block i (barrier-free: weights resident, halo complete)
+            const int i = (phase - g) >> 1;
+            if (i < nmine) {
+                if (RES) {
+                    int img, y0, x0;
+                    tile_coords(block_of(i), img, y0, x0);
+                    const half_t* rbase = p.res + ((int64_t)(img * p.res_hp + y0 + p.res_ring) * p.res_wp + x0 + p.res_ring) * 64;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rrel = (px_row(j) * p.res_wp + px_col(j)) * 64 + fq * 16;
+                        rv[j][0] = *(const half8*)(rbase + rrel);
+                        rv[j][1] = *(const half8*)(rbase + rrel + 8);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][j] = *(const floatx4*)(bias_lds + fq * 16 + a * 4);
+                auto load_frags = [&](int hs, half8 (&af)[4], half8 (&bf)[4]) {
+                    const int tap = hs >> 1, kk = hs & 1;
+                    const int tapoff = (tap / 3) * HWD + (tap % 3), dx = tap % 3;
+                    const char* pa = hb + a_lane_off + tapoff * 128 + (((fq + 4 * kk) ^ ((fr + dx) & 6)) << 4);
+                    const char* pb = wl + tap * 8192 + b_lane_off + (((fq + 4 * kk) ^ bswz) << 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) af[j] = *(const half8*)(pa + (TW == 16 ? j * HWD : (j >> 1) * HWD + (j & 1) * 16) * 128);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) bf[a] = *(const half8*)(pb + a * 2048);
+                };
+                half8 fa[2][4], fb[2][4];
+                load_frags(0, fa[0], fb[0]);
+#pragma unroll
+                for (int hs = 0; hs < 18; ++hs) {
+                    if (hs + 1 < 18) load_frags(hs + 1, fa[(hs + 1) & 1], fb[(hs + 1) & 1]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[hs & 1][a], fa[hs & 1][j], acc[a][j], 0, 0, 0);
+                    if (hs + 1 < 18) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // ---- service phase: finish block i, fetch the halo of block i + 1, wait for it (the partner group is multiplying)
+            const int i = (phase - g - 1) >> 1;
+            if (phase - g - 1 >= 0 && i < nmine) {
+                int img, y0, x0;
+                tile_coords(block_of(i), img, y0, x0);
+                half_t* obase = p.out + ((int64_t)(img * p.out_hp + y0 + p.out_ring) * p.out_wp + x0 + p.out_ring) * 64;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        half8 hv;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float v = acc[2 * h + (k >> 2)][j][k & 3];
+                            if (RES) v += (float)rv[j][h][k];
+                            hv[k] = (half_t)(RELU ? fmaxf(v, 0.f) : v);
+                        }
+                        *(half8*)(obase + (px_row(j) * p.out_wp + px_col(j)) * 64 + fq * 16 + h * 8) = hv;
+                    }
+                if (i + 1 < nmine) issue_halo(block_of(i + 1));
+            }
+            hl_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    hl_wait_vmcnt<0>();
+}
+
 template <int TW, bool RELU, bool RES>
 int c64_launch(const HaloParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW, HROWS = (TH + 2) * (TW + 2), HBYTES = (HROWS + 7) / 8 * 1024;
-    constexpr int lds = 9 * 64 * 128 + 2 * HBYTES + 1024;
+    constexpr int lds = 9 * 64 * 128 + 2 * HBYTES + 1024 + 256;  // (+256: the duo kernel's bias)
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (p.h % TH || p.w % TW) return -2205;  // whole pixel blocks only (block-independent addressing)
     static bool attr_done = false;
@@ -623,6 +782,18 @@ int c64_launch(const HaloParams& p, hipStream_t stream) {
         free(h);
         (void)hipFree(dev);
         return 0;
+    }
+    const char* duo_env = getenv("VTD_C64_DUO");  // tests: 0 = the one-group kernel (read per launch so a test can flip it)
+    const bool duo = !(duo_env && duo_env[0] == '0');
+    if (duo) {
+        static bool attr_duo = false;
+        if (!attr_duo) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_duo_kernel<TW, RELU, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return -(int)e;
+            attr_duo = true;
+        }
+        hipLaunchKernelGGL((conv3x3_c64_duo_kernel<TW, RELU, RES>), dim3(grid), dim3(512), lds, stream, p);
+        return -(int)hipGetLastError();
     }
     hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<TW, RELU, RES>), dim3(grid), dim3(256), lds, stream, p);
     return -(int)hipGetLastError();
