@@ -95,7 +95,8 @@ def test_asynchronous_kernels_are_bitwise_repeatable_under_load(hip):
     times on the same batch while the recogniser hammers a second stream, at two batch sizes, and demand identical bits."""
     from vtd_amd.engine import DetectorEngine, DeviceFrames, RecognizerEngine
     sd = weights.margin_detector_state_dict("resnet18", 0)
-    eng = DetectorEngine("resnet18", sd, max_batch=32)
+    opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_SOAK_OPTIONS", "").split(",") if kv)}  # bisecting aid
+    eng = DetectorEngine("resnet18", sd, max_batch=32, options=opts or None)
     rec = RecognizerEngine(97, weights.calibrated_crnn_state_dict(11), max_crops=512)
     crops = torch.from_numpy(synth.glyph_batch(5, 272)).cuda()
     side = torch.cuda.Stream()

@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, HT_WG_PER_CU) void head_tail_kernel(const Head
         // are outstanding.  (Output stores share the counter and retire out of order with the loads: every store that could
         // still be outstanding here is YOUNGER than tile k's loads, so it can only make this wait longer, never shorter than needed.)
         if (k + HT_NST - 1 <= nt) ht_wait_vmcnt<2 * (HT_NST - 2)>(); else ht_wait_vmcnt<0>();
+        // this wave's otile writes of tile k-1 must have reached LDS before anyone reads them behind the barrier: a raw s_barrier
+        // orders nothing by itself (found by the repeatability soak in tests/test_gpu_tuning.py: rare stale 16-byte pieces under load)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // tile k is in LDS for every wave; everyone is done with tile k-1's fragments and its otile
         if (k > 0) store_out(tile - stride, ob ^ 1);
         if (k + HT_NST - 1 < nt) issue(tile + (HT_NST - 1) * stride, st == 0 ? HT_NST - 1 : st - 1);
