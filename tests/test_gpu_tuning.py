@@ -88,24 +88,25 @@ def test_table_entries_steer_the_launch_and_invalid_ones_are_ignored(hip, monkey
         eng.close()
 
 
-def test_asynchronous_kernels_are_bitwise_repeatable_under_load(hip):
+@pytest.mark.parametrize("backbone,batches,reps", [("resnet18", (32, 5), 24), ("resnet50", (8,), 12)])
+def test_asynchronous_kernels_are_bitwise_repeatable_under_load(hip, backbone, batches, reps):
     """Every hot kernel keeps loads in flight across barriers behind counted `s_waitcnt vmcnt(N)` (LDS-DMA rings in stem_pool,
     head_tail, pointwise, conv_igemm, the halo kernels).  A read that is ordered only by luck passes a parity check whenever the
     DMA happens to land first; what exposes it is timing noise.  Run the B = 32 detector graph (the shipped kernel selection) 24
     times on the same batch while the recogniser hammers a second stream, at two batch sizes, and demand identical bits."""
     from vtd_amd.engine import DetectorEngine, DeviceFrames, RecognizerEngine
-    sd = weights.margin_detector_state_dict("resnet18", 0)
+    sd = weights.margin_detector_state_dict(backbone, 0)
     opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_SOAK_OPTIONS", "").split(",") if kv)}  # bisecting aid
-    eng = DetectorEngine("resnet18", sd, max_batch=32, options=opts or None)
+    eng = DetectorEngine(backbone, sd, max_batch=max(batches), options=opts or None)
     rec = RecognizerEngine(97, weights.calibrated_crnn_state_dict(11), max_crops=512)
     crops = torch.from_numpy(synth.glyph_batch(5, 272)).cuda()
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     try:
-        for n in (32, 5):
+        for n in batches:
             frames = DeviceFrames(np.stack([synth.text_frame(300 + i)[0] for i in range(n)]))
             ref, ref_logits = None, None
-            for it in range(24):
+            for it in range(reps):
                 with torch.cuda.stream(side):
                     logits = rec.forward_logits(crops)
                     if it % 3 == 0:
