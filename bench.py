@@ -317,7 +317,8 @@ def main():
                 return max(hits, key=lambda h: h["launches"]) if hits else None
 
             # launch-slot description (vtd_api.cpp) -> device kernel symbol of exactly that variant
-            symbol = next((sym for key, sym in (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_halo256", "head_entry_halo256_kernel("),
+            symbol = next((sym for key, sym in (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
+                                                ("head_entry_halo256", "head_entry_halo256_kernel<false>("),
                                                 ("head_entry_halo ", "head_entry_halo_kernel<"),
                                                 ("classed", "true>(")) if key in name), None)
             parts = [v for v in [pick(symbol) if symbol else None] if v]

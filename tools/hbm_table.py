@@ -15,7 +15,9 @@ import sys
 
 WANT = {"stem_pool_kernel": "stem_pool", "head_tail_kernel": "head_tail", "pointwise128_kernel": "pointwise128",
         "preprocess_fast_kernel": "preprocess_fast", "conv3x3_c64_persistent_kernel<16, true, false>": "conv3x3_c64_persistent (no residual)",
-        "conv3x3_c64_persistent_kernel<16, true, true>": "conv3x3_c64_persistent (+residual)", "head_entry_halo256_kernel": "head_entry_halo256",
+        "conv3x3_c64_persistent_kernel<16, true, true>": "conv3x3_c64_persistent (+residual)",
+        "conv3x3_c64_duo_kernel<16, true, false>": "conv3x3_c64_duo (layer 1, no residual)",
+        "conv3x3_c64_duo_kernel<16, true, true>": "conv3x3_c64_duo (layer 1, +residual)", "head_entry_halo256_kernel": "head_entry_halo256",
         "crnn_conv1_pool_kernel": "crnn_conv1_pool", "maxpool_kernel": "maxpool (CRNN)", "lstm_recurrence_kernel": "lstm_recurrence"}
 ALONE = {"stem_pool": "stem_pool", "head_tail": "head_tail", "pointwise128": "pointwise128", "head_entry_halo256": "head_entry_halo256"}
 ACHIEVABLE_TBS = 6.3   # rocprof-measured streaming ceiling on this part (MI355X_MICROARCH.md), of 8 TB/s nominal
