@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     constexpr bool UNEVEN = (BM / 16) % WM != 0;
     static_assert(BM % 16 == 0 && (BM / 16 - (WM - 1) * FM) >= 1, "tile height");
     static_assert(!UNEVEN || (!CLASSED && BN != 256), "uneven wave rows finish from registers only");
-    static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8), "tile/wave shape");
+    static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8 || NW == 16), "tile/wave shape");
     static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
     constexpr int EPI_ROW = BN * 4 + 16;  // fp32 tile row stride (bytes), padded by one 16-byte slot
 
@@ -603,7 +603,11 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //   13  272x128   8 (2x4) 3     150 KB   1      x 256 channels = 494 tiles of 208 (two rounds at 0.81 of the 256-row tile's time each)
 //                                               instead of 400 of 256 (two rounds for 1.56); 69 632 rows = exactly 256 tiles of 272 per
 //                                               128 channels.  Wave rows of 7 + 6 / 9 + 8 fragments; register epilogue only
-int vtd_conv_num_configs() { return 14; }
+//   14  256x128   16 (4x4) 3    144 KB   1      the 256 x 128 tile on FOUR waves per SIMD (64 x 32 per wave, 3 LDS-DMA instructions per wave
+//                                               and K-step instead of 6).  Measured equal to configuration 0 on every layer (tools/gpu_tiles.sh),
+//                                               as was a 208-row tile with 12 % fewer MFMAs: a K-step of this kernel costs what its 48 one-KB
+//                                               LDS-DMA instructions per CU cost (~40 cycles each), whoever issues them
+int vtd_conv_num_configs() { return 15; }
 
 // plain NHWC fp16 output with bias / residual / ReLU only: what the register epilogue (and so configurations 12 / 13) can finish
 static bool epi_direct_eligible(const ConvParams& p) {
@@ -615,7 +619,7 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
     if (p.plist) return ((cfg == 8 || cfg == 9) || ((cfg == 10 || cfg == 11) && p.plist_b && p.tile_combo_b && p.tiles_per_img_b > 0)) && p.cout_pad % 64 == 0;
     switch (cfg) {
-        case 0: case 1: case 2: return p.cout_pad % 128 == 0;
+        case 0: case 1: case 2: case 14: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
         case 12: case 13: {
             const char* e = getenv("VTD_EPI_DIRECT");
@@ -675,6 +679,7 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         case 7: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
+        case 14: return launch_cfg<256, 128, 4, 4, 3>(p, stream);
         case 12: return launch_cfg<208, 128, 2, 4, 3>(p, stream);
         case 13: return launch_cfg<272, 128, 2, 4, 3>(p, stream);
         default: {
