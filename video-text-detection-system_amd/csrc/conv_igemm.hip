@@ -66,7 +66,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     constexpr int FN = TN / 16;
     constexpr bool UNEVEN = (BM / 16) % WM != 0;
     static_assert(BM % 16 == 0 && (BM / 16 - (WM - 1) * FM) >= 1, "tile height");
-    static_assert(!UNEVEN || (!CLASSED && BN != 256), "uneven wave rows finish from registers only");
+    constexpr bool HEAD_TILE = BM == 64 && BN == 256;       // configuration 7: the fused DB-head tail needs all 256 columns of a pixel
+    constexpr bool DIRECT_ONLY = UNEVEN || BM * (BN * 4 + 16) > 160 * 1024;  // no room (or no code) for the fp32 staging tile
+    static_assert(!DIRECT_ONLY || (!CLASSED && !HEAD_TILE), "these tile shapes finish from registers only");
     static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8 || NW == 16), "tile/wave shape");
     static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
     constexpr int EPI_ROW = BN * 4 + 16;  // fp32 tile row stride (bytes), padded by one 16-byte slot
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Register epilogue (plain NHWC output, bias / residual / ReLU only): decided by the launcher, uniform over the grid
-    const bool direct = !CLASSED && BN != 256 && p.epi_direct != 0;
+    const bool direct = !CLASSED && !(BM == 64 && BN == 256) && p.epi_direct != 0;
 
     // ---- loader state: each lane owns one 16-byte chunk slot of A_INST + B_INST rows
     const int lrow = lane >> 3;
@@ -244,85 +246,107 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     };
 
     const int nk = p.K >> 6;
-    constexpr int L0 = (LOADS + 1) / 2, L1 = LOADS - L0;
-    constexpr int P2 = STAGES == 3 ? L1 : 0;      // loads issued under the MFMAs of half 0 (second part of K-step s+2)
-    constexpr int P4 = STAGES == 3 ? L0 : LOADS;  // loads issued after the barrier (first part of K-step s+3 / all of K-step s+2)
-    half8 fa[2][FM], fb[2][FN];
-
-    // prologue: K-steps 0 and 1 entirely, with 3 stages also the first part of K-step 2
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (STAGES == 3 && nk > 2) {
-        begin_step(2);
+    constexpr bool PIPE = FM * FN < 32;  // 8 x 4 fragment tiles (256 x 256 on 8 waves): 128 accumulator registers leave no room for a second fragment set
+    if constexpr (!PIPE) {
+        // plain two-buffer loop: wait, barrier, next K-step's loads leave, then two half-steps of read-then-multiply (the partner wave
+        // on the SIMD covers the read latency); what this shape buys is pieces per MFMA, not issue overlap
+        static_assert(STAGES == 2 && !UNEVEN, "big register tiles: two LDS stages");
+        half8 af[FM], bf[FN];
+        stage(0, 0);
+        int buf = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // K-step ks landed for every wave; everyone finished reading the other buffer
+            if (ks + 1 < nk) stage(ks + 1, buf ^ 1);
+            const char* sb = smem + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < L0; ++j) issue_load(j, 2, 2);
-    }
-    if (STAGES == 3 && nk > 2) wait_vmcnt<LOADS + L0>(); else if (nk > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    read_frags(smem, 0, fa[0], fb[0]);
-
-    // one iteration; HAS2 / HAS4: the loads of part 2 / part 4 exist (compile-time, so the load / MFMA interleave stays pinned)
-    auto iteration = [&](int s, int buf, auto has2_c, auto has4_c) {
-        constexpr bool HAS2 = decltype(has2_c)::value != 0, HAS4 = decltype(has4_c)::value != 0;
-        const char* sb = smem + buf * STAGE;
-        int b1 = buf + 1; b1 = b1 >= STAGES ? b1 - STAGES : b1;   // buffer of K-step s+1
-        int b2 = b1 + 1; b2 = b2 >= STAGES ? b2 - STAGES : b2;   // 3 stages: buffer of K-step s+2 (2 stages: == buf)
-        read_frags(sb, 1, fa[1], fb[1]);
-        if constexpr (HAS2 && P2 > 0) {
-            mfma_half(fa[0], fb[0], IntC<P2>{}, s + 2, b2, L0);
-            end_step();
-            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // the fragment reads first,
-            pin_loads_between_mfmas<FM * FN, P2>();                    // then MFMA groups with one LDS-DMA after each
-        } else {
-            mfma_half(fa[0], fb[0], IntC<0>{}, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
-            pin_loads_between_mfmas<FM * FN, 0>();
+            for (int kk = 0; kk < 2; ++kk) {
+                read_frags(sb, kk, af, bf);
+                mfma_half(af, bf, IntC<0>{}, 0, 0, 0);
+            }
+            buf ^= 1;
         }
-        if (s + 1 >= nk) {  // last K-step: nothing to publish or prefetch
-            mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
-            return;
+    } else {
+        constexpr int L0 = (LOADS + 1) / 2, L1 = LOADS - L0;
+        constexpr int P2 = STAGES == 3 ? L1 : 0;      // loads issued under the MFMAs of half 0 (second part of K-step s+2)
+        constexpr int P4 = STAGES == 3 ? L0 : LOADS;  // loads issued after the barrier (first part of K-step s+3 / all of K-step s+2)
+        half8 fa[2][FM], fb[2][FN];
+
+        // prologue: K-steps 0 and 1 entirely, with 3 stages also the first part of K-step 2
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        if (STAGES == 3 && nk > 2) {
+            begin_step(2);
+    #pragma unroll
+            for (int j = 0; j < L0; ++j) issue_load(j, 2, 2);
         }
-        // K-step s+1 has landed when only K-step s+2's loads (all issued by now) are outstanding
-        if constexpr (HAS2 && STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
-        // This wave's reads of K-step s must be complete before the barrier (the buffer is refilled behind it).  Asking for the
-        // registers makes hipcc place that wait HERE, where nothing younger is outstanding; left alone it waits for them in front of
-        // the MFMAs below as lgkmcnt(0), which would also sit out the fragment reads issued just before -- the prefetch would be lost.
-#pragma unroll
-        for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(fa[1][j]));
-#pragma unroll
-        for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[1][i]));
-#ifdef VTD_CONV_EXPERIMENT
-        if (p.dbg != 4)
-#endif
+        if (STAGES == 3 && nk > 2) wait_vmcnt<LOADS + L0>(); else if (nk > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (HAS4 && STAGES == 2) stage(s + 2, buf);  // one K-step of slack only: the loads leave first
-        read_frags(smem + b1 * STAGE, 0, fa[0], fb[0]);
-        if constexpr (HAS4 && STAGES == 3) {
-            begin_step(s + 3);
-            mfma_half(fa[1], fb[1], IntC<P4>{}, s + 3, buf, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
-            pin_loads_between_mfmas<FM * FN, P4>();
-        } else {
-            mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
-            pin_loads_between_mfmas<FM * FN, 0>();
-        }
-    };
+        read_frags(smem, 0, fa[0], fb[0]);
 
-    int buf = 0, s = 0;
-    // steady state: both load groups exist (3 stages: K-steps s+2 and s+3; 2 stages: K-step s+2)
-    for (; s + STAGES < nk; ++s) {
-        iteration(s, buf, IntC<1>{}, IntC<1>{});
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-    }
-    if (STAGES == 3 && s + 2 < nk) {  // K-step s+2 is the last one: its second part still has to leave
-        iteration(s, buf, IntC<1>{}, IntC<0>{});
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
-        ++s;
-    }
-    for (; s < nk; ++s) {  // drain: nothing left to fetch
-        iteration(s, buf, IntC<0>{}, IntC<0>{});
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        // one iteration; HAS2 / HAS4: the loads of part 2 / part 4 exist (compile-time, so the load / MFMA interleave stays pinned)
+        auto iteration = [&](int s, int buf, auto has2_c, auto has4_c) {
+            constexpr bool HAS2 = decltype(has2_c)::value != 0, HAS4 = decltype(has4_c)::value != 0;
+            const char* sb = smem + buf * STAGE;
+            int b1 = buf + 1; b1 = b1 >= STAGES ? b1 - STAGES : b1;   // buffer of K-step s+1
+            int b2 = b1 + 1; b2 = b2 >= STAGES ? b2 - STAGES : b2;   // 3 stages: buffer of K-step s+2 (2 stages: == buf)
+            read_frags(sb, 1, fa[1], fb[1]);
+            if constexpr (HAS2 && P2 > 0) {
+                mfma_half(fa[0], fb[0], IntC<P2>{}, s + 2, b2, L0);
+                end_step();
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // the fragment reads first,
+                pin_loads_between_mfmas<FM * FN, P2>();                    // then MFMA groups with one LDS-DMA after each
+            } else {
+                mfma_half(fa[0], fb[0], IntC<0>{}, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                pin_loads_between_mfmas<FM * FN, 0>();
+            }
+            if (s + 1 >= nk) {  // last K-step: nothing to publish or prefetch
+                mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
+                return;
+            }
+            // K-step s+1 has landed when only K-step s+2's loads (all issued by now) are outstanding
+            if constexpr (HAS2 && STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+            // This wave's reads of K-step s must be complete before the barrier (the buffer is refilled behind it).  Asking for the
+            // registers makes hipcc place that wait HERE, where nothing younger is outstanding; left alone it waits for them in front of
+            // the MFMAs below as lgkmcnt(0), which would also sit out the fragment reads issued just before -- the prefetch would be lost.
+    #pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" ::"v"(fa[1][j]));
+    #pragma unroll
+            for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[1][i]));
+    #ifdef VTD_CONV_EXPERIMENT
+            if (p.dbg != 4)
+    #endif
+            __builtin_amdgcn_s_barrier();
+            if constexpr (HAS4 && STAGES == 2) stage(s + 2, buf);  // one K-step of slack only: the loads leave first
+            read_frags(smem + b1 * STAGE, 0, fa[0], fb[0]);
+            if constexpr (HAS4 && STAGES == 3) {
+                begin_step(s + 3);
+                mfma_half(fa[1], fb[1], IntC<P4>{}, s + 3, buf, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                pin_loads_between_mfmas<FM * FN, P4>();
+            } else {
+                mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                pin_loads_between_mfmas<FM * FN, 0>();
+            }
+        };
+
+        int buf = 0, s = 0;
+        // steady state: both load groups exist (3 stages: K-steps s+2 and s+3; 2 stages: K-step s+2)
+        for (; s + STAGES < nk; ++s) {
+            iteration(s, buf, IntC<1>{}, IntC<1>{});
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
+        if (STAGES == 3 && s + 2 < nk) {  // K-step s+2 is the last one: its second part still has to leave
+            iteration(s, buf, IntC<1>{}, IntC<0>{});
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+            ++s;
+        }
+        for (; s < nk; ++s) {  // drain: nothing left to fetch
+            iteration(s, buf, IntC<0>{}, IntC<0>{});
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
     }
 
     // ---- register epilogue.  The LDS round trip below (fp32 tile out, 8-channel rows back in, two workgroup barriers, a pixel
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // lane already holds 8 consecutive channels of each of its FM pixels per pair of fragment blocks: (acc + bias) + residual, ReLU,
     // one fp16 rounding -- the same operations in the same order as below, so both paths give identical bits -- and one 16-byte
     // store; the four lane groups of a pixel write 64 contiguous bytes.  No barrier: a wave leaves as soon as its own MFMAs are done.
-    if constexpr (!CLASSED && BN != 256 && (FN % 2) == 0) {
+    if constexpr (!CLASSED && !HEAD_TILE && (FN % 2) == 0) {
         if (direct) {
             const int fq = lane >> 4;
             int64_t o_off[FM], r_off[FM];
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         }
     }
 
-    if constexpr (UNEVEN) return;  // (unreachable: the launcher admits these tile heights only with the register epilogue)
+    if constexpr (DIRECT_ONLY) return;  // (unreachable: the launcher admits these tile shapes only with the register epilogue)
 #ifdef VTD_CONV_EXPERIMENT
     if (p.dbg == 5) {  // no epilogue: keep the accumulators alive with one store per wave
         float t = 0.f;
@@ -425,7 +449,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
     __syncthreads();
 
-    if constexpr (BN == 256) {
+    if constexpr (HEAD_TILE) {
         // ---- fused DB-head tail (EPI_HEAD_FINAL): one thread = one (input pixel, 2x2 block) = 64 channels of the
         // ConvT1 output -> BN/ReLU -> ConvT(64->1) -> sigmoid -> a 2x2 patch of the probability map.
         // A quad of lanes shares one (pixel, block): lane q of the quad owns channels 16q..16q+15, keeps the matching
@@ -570,8 +594,8 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;  // (classed: vtd_launch_conv set M for this tile height)
     const int tiles_n = p.cout_pad / BN;
     constexpr int stage_bytes = STAGES * (BM + BN) * 128;
-    constexpr bool uneven = (BM / 16) % WM != 0;  // register epilogue only: no fp32 staging tile
-    constexpr int epi_bytes = uneven ? 0 : BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
+    constexpr bool direct_only = (BM / 16) % WM != 0 || BM * (BN * 4 + 16) > 160 * 1024;  // register epilogue only: no fp32 staging tile
+    constexpr int epi_bytes = direct_only ? 0 : BM * (BN * 4 + 16) + BM * 8 + (BN == 256 ? 1024 : 0);
     constexpr int lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -607,7 +631,9 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //                                               and K-step instead of 6).  Measured equal to configuration 0 on every layer (tools/gpu_tiles.sh),
 //                                               as was a 208-row tile with 12 % fewer MFMAs: a K-step of this kernel costs what its 48 one-KB
 //                                               LDS-DMA instructions per CU cost (~40 cycles each), whoever issues them
-int vtd_conv_num_configs() { return 15; }
+//   15  256x256   8 (2x4) 2     128 KB   1      64 LDS-DMA pieces per K-step for twice the MFMAs of the 256 x 128 tile (32 per 256 x 128
+//                                               equivalent instead of 48): for launches with enough 256 x 256 tiles.  Register epilogue only
+int vtd_conv_num_configs() { return 16; }
 
 // plain NHWC fp16 output with bias / residual / ReLU only: what the register epilogue (and so configurations 12 / 13) can finish
 static bool epi_direct_eligible(const ConvParams& p) {
@@ -621,9 +647,9 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     switch (cfg) {
         case 0: case 1: case 2: case 14: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
-        case 12: case 13: {
+        case 12: case 13: case 15: {
             const char* e = getenv("VTD_EPI_DIRECT");
-            return p.cout_pad % 128 == 0 && epi_direct_eligible(p) && !(e && e[0] == '0');
+            return p.cout_pad % (cfg == 15 ? 256 : 128) == 0 && epi_direct_eligible(p) && !(e && e[0] == '0');
         }
         default: return false;
     }
@@ -680,6 +706,7 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
         case 14: return launch_cfg<256, 128, 4, 4, 3>(p, stream);
+        case 15: return launch_cfg<256, 256, 2, 4, 2>(p, stream);
         case 12: return launch_cfg<208, 128, 2, 4, 3>(p, stream);
         case 13: return launch_cfg<272, 128, 2, 4, 3>(p, stream);
         default: {
