@@ -150,6 +150,55 @@ __global__ __launch_bounds__(256) void trocr_ln_kernel(float* __restrict__ x, co
     }
 }
 
+// The same with 16-byte accesses (C % 256 == 0, 16-byte aligned rows): a lane owns float4 number i*64 + lane of the row, 3-4 loads
+// per operand instead of 12-16.  At the decoder's 272 rows the kernel is three dependent memory round trips whatever the row length;
+// fewer instructions in each is what is left to take.
+template <int MAXV4>
+__global__ __launch_bounds__(256) void trocr_ln4_kernel(float* __restrict__ x, const float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, half_t* __restrict__ out16, float* __restrict__ out32,
+                                                        int rows, int C, float eps, int mode) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    floatx4 v[MAXV4];
+    const int nv = C / 256;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i) {
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            floatx4 t = *(const floatx4*)(x + (int64_t)row * C + c);
+            if (mode != 0 && y) t += *(const floatx4*)(y + (int64_t)row * ldy + c);
+            v[i] = t;
+            sum += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i)
+        if (i < nv) {
+            const floatx4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i) {
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            const floatx4 g = *(const floatx4*)(gamma + c), b = *(const floatx4*)(beta + c);
+            const floatx4 n = (v[i] - mean) * rstd * g + b;
+            if (mode == 1) *(floatx4*)(x + (int64_t)row * C + c) = v[i];
+            if (mode == 2) *(floatx4*)(x + (int64_t)row * C + c) = n;
+            if (out16) *(half4*)(out16 + (int64_t)row * C + c) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
+            if (out32) *(floatx4*)(out32 + (int64_t)row * C + c) = n;
+        }
+    }
+}
+
 // Encoder self-attention.  qkv: [B][T][3*C] fp16 (q | k | v, head h at columns h*64).  Workgroup = 64 queries of one (b, head),
 // wave = 16 queries; keys in blocks of 32 staged in LDS (K row-major, V transposed).
 constexpr int ATT_KPAD = 72;   // halfs per K row in LDS (64 + 8: conflict-free 16-byte fragment reads)
@@ -403,6 +452,13 @@ int vtd_launch_trocr_ln(float* x, const float* y, int ldy, const float* gamma, c
                         float eps, int mode, hipStream_t s) {
     if (rows <= 0 || (C & 63) || C > 2048) return -2403;
     const dim3 grid((rows + 3) / 4), block(256);
+    const bool al = !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !(ldy & 3) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15) &&
+                    !((uintptr_t)out16 & 7) && !((uintptr_t)out32 & 15);
+    if (!(C & 255) && al) {
+        if (C <= 1024) hipLaunchKernelGGL(trocr_ln4_kernel<4>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
+        else hipLaunchKernelGGL(trocr_ln4_kernel<8>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
+        return -(int)hipGetLastError();
+    }
     if (C <= 1024) hipLaunchKernelGGL(trocr_ln_kernel<16>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
     else hipLaunchKernelGGL(trocr_ln_kernel<32>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
     return -(int)hipGetLastError();
