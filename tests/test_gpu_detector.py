@@ -300,7 +300,7 @@ def test_register_epilogue_bit_identical_to_lds_epilogue(hip, monkeypatch):
     assert np.array_equal(outs["1"][0], outs["0"][0])
 
 
-@pytest.mark.parametrize("cfg", [12, 13, 14, 15, 0, 5])
+@pytest.mark.parametrize("cfg", [12, 13, 14, 15, 16, 0, 5])
 def test_implicit_gemm_tile_heights_bit_identical(hip, monkeypatch, cfg):
     """Tile configurations 12 / 13 (208- and 272-row tiles, wave rows of 7 + 6 / 9 + 8 fragments, spare LDS-DMA instructions
     re-fetching the last piece) forced wherever they are valid, on the layer-by-layer graph at a batch whose row counts are not
@@ -322,7 +322,7 @@ def test_implicit_gemm_tile_heights_bit_identical(hip, monkeypatch, cfg):
         finally:
             eng.close()
         outs[mode] = (prob, taps, names)
-    want = {12: "208,128,s3", 13: "272,128,s3", 14: "256,128,s3,16w", 15: "256,256,s2", 0: "256,128,s3", 5: "128,64,s2"}[cfg]
+    want = {12: "208,128,s3", 13: "272,128,s3", 14: "256,128,s3,16w", 15: "256,256,s2", 16: "128,64,s6", 0: "256,128,s3", 5: "128,64,s2"}[cfg]
     assert sum(want in n for n in outs[str(cfg)][2]) >= (6 if cfg == 15 else 8), outs[str(cfg)][2]   # 15 needs 256 output channels
     for a, b, n in zip(outs[str(cfg)][1], outs[None][1], ("c2", "c3", "c4", "c5", "p2")):
         assert np.array_equal(a, b), n

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     constexpr bool DIRECT_ONLY = UNEVEN || BM * (BN * 4 + 16) > 160 * 1024;  // no room (or no code) for the fp32 staging tile
     static_assert(!DIRECT_ONLY || (!CLASSED && !HEAD_TILE), "these tile shapes finish from registers only");
     static_assert(A_INST >= 1 && B_INST >= 1 && (NW == 4 || NW == 8 || NW == 16), "tile/wave shape");
-    static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
+    static_assert(STAGES >= 2 && STAGES <= 6, "pipeline depth");
     constexpr int EPI_ROW = BN * 4 + 16;  // fp32 tile row stride (bytes), padded by one 16-byte slot
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,19 +268,35 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         }
     } else {
         constexpr int L0 = (LOADS + 1) / 2, L1 = LOADS - L0;
-        constexpr int P2 = STAGES == 3 ? L1 : 0;      // loads issued under the MFMAs of half 0 (second part of K-step s+2)
-        constexpr int P4 = STAGES == 3 ? L0 : LOADS;  // loads issued after the barrier (first part of K-step s+3 / all of K-step s+2)
+        // D = K-steps a load is issued ahead of its use.  2 stages: 1 (all loads of K-step s+2 leave right after the barrier that frees their
+        // buffer).  3 and more: STAGES - 1, spread over the MFMAs (second part of K-step s+D under half 0, first part of K-step s+D+1 under
+        // half 1).  Deep rings (6 stages of the 128 x 64 tile = 144 KB) are for launches with a handful of workgroups and a long K, where a
+        // K-step is a memory round trip and nothing else (the TrOCR decoder's GEMMs at 272 rows: 48 workgroups, 16 K-steps).
+        constexpr int D = STAGES >= 3 ? STAGES - 1 : 1;
+        constexpr int P2 = STAGES >= 3 ? L1 : 0;
+        constexpr int P4 = STAGES >= 3 ? L0 : LOADS;
+        static_assert((D - 1) * LOADS + L0 < 64, "vmcnt immediate");
         half8 fa[2][FM], fb[2][FN];
 
-        // prologue: K-steps 0 and 1 entirely, with 3 stages also the first part of K-step 2
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        if (STAGES == 3 && nk > 2) {
-            begin_step(2);
+        // prologue: K-steps 0 .. D-1 entirely (2 stages: 0 and 1), with 3 and more stages also the first part of K-step D
+        if constexpr (STAGES >= 3) {
     #pragma unroll
-            for (int j = 0; j < L0; ++j) issue_load(j, 2, 2);
+            for (int a = 0; a < D; ++a)
+                if (a < nk) stage(a, a);
+            if (nk > D) {
+                begin_step(D);
+    #pragma unroll
+                for (int j = 0; j < L0; ++j) issue_load(j, D, D);
+                wait_vmcnt<(D - 1) * LOADS + L0>();
+            } else if (STAGES == 3 && nk > 1) {
+                wait_vmcnt<LOADS>();
+            } else {
+                wait_vmcnt<0>();
+            }
+        } else {
+            stage(0, 0);
+            if (nk > 1) { stage(1, 1); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
         }
-        if (STAGES == 3 && nk > 2) wait_vmcnt<LOADS + L0>(); else if (nk > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         read_frags(smem, 0, fa[0], fb[0]);
 
@@ -289,10 +305,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             constexpr bool HAS2 = decltype(has2_c)::value != 0, HAS4 = decltype(has4_c)::value != 0;
             const char* sb = smem + buf * STAGE;
             int b1 = buf + 1; b1 = b1 >= STAGES ? b1 - STAGES : b1;   // buffer of K-step s+1
-            int b2 = b1 + 1; b2 = b2 >= STAGES ? b2 - STAGES : b2;   // 3 stages: buffer of K-step s+2 (2 stages: == buf)
+            const int bD = buf == 0 ? STAGES - 1 : buf - 1;         // buffer of K-step s+D (3 and more stages)
             read_frags(sb, 1, fa[1], fb[1]);
             if constexpr (HAS2 && P2 > 0) {
-                mfma_half(fa[0], fb[0], IntC<P2>{}, s + 2, b2, L0);
+                mfma_half(fa[0], fb[0], IntC<P2>{}, s + D, bD, L0);
                 end_step();
                 __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // the fragment reads first,
                 pin_loads_between_mfmas<FM * FN, P2>();                    // then MFMA groups with one LDS-DMA after each
@@ -305,8 +321,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
                 mfma_half(fa[1], fb[1], IntC<0>{}, 0, 0, 0);
                 return;
             }
-            // K-step s+1 has landed when only K-step s+2's loads (all issued by now) are outstanding
-            if constexpr (HAS2 && STAGES == 3) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+            // K-step s+1 has landed when only the loads of K-steps s+2 .. s+D (all issued by now) are outstanding
+            if constexpr (HAS2 && STAGES >= 3) wait_vmcnt<(D - 1) * LOADS>(); else wait_vmcnt<0>();
             // This wave's reads of K-step s must be complete before the barrier (the buffer is refilled behind it).  Asking for the
             // registers makes hipcc place that wait HERE, where nothing younger is outstanding; left alone it waits for them in front of
             // the MFMAs below as lgkmcnt(0), which would also sit out the fragment reads issued just before -- the prefetch would be lost.
@@ -320,9 +336,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             __builtin_amdgcn_s_barrier();
             if constexpr (HAS4 && STAGES == 2) stage(s + 2, buf);  // one K-step of slack only: the loads leave first
             read_frags(smem + b1 * STAGE, 0, fa[0], fb[0]);
-            if constexpr (HAS4 && STAGES == 3) {
-                begin_step(s + 3);
-                mfma_half(fa[1], fb[1], IntC<P4>{}, s + 3, buf, 0);
+            if constexpr (HAS4 && STAGES >= 3) {
+                begin_step(s + D + 1);
+                mfma_half(fa[1], fb[1], IntC<P4>{}, s + D + 1, buf, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
                 pin_loads_between_mfmas<FM * FN, P4>();
             } else {
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             iteration(s, buf, IntC<1>{}, IntC<1>{});
             buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
-        if (STAGES == 3 && s + 2 < nk) {  // K-step s+2 is the last one: its second part still has to leave
+        if (STAGES >= 3 && s + D < nk) {  // K-step s+D is the last one: its second part still has to leave
             iteration(s, buf, IntC<1>{}, IntC<0>{});
             buf = buf + 1 == STAGES ? 0 : buf + 1;
             ++s;
@@ -633,7 +649,8 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
 //                                               LDS-DMA instructions per CU cost (~40 cycles each), whoever issues them
 //   15  256x256   8 (2x4) 2     128 KB   1      64 LDS-DMA pieces per K-step for twice the MFMAs of the 256 x 128 tile (32 per 256 x 128
 //                                               equivalent instead of 48): for launches with enough 256 x 256 tiles.  Register epilogue only
-int vtd_conv_num_configs() { return 16; }
+//   16  128x64    4     6       144 KB   1      six LDS stages: five K-steps of loads in flight, for launches of a few workgroups with a long K
+int vtd_conv_num_configs() { return 17; }
 
 // plain NHWC fp16 output with bias / residual / ReLU only: what the register epilogue (and so configurations 12 / 13) can finish
 static bool epi_direct_eligible(const ConvParams& p) {
@@ -646,7 +663,7 @@ bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.plist) return ((cfg == 8 || cfg == 9) || ((cfg == 10 || cfg == 11) && p.plist_b && p.tile_combo_b && p.tiles_per_img_b > 0)) && p.cout_pad % 64 == 0;
     switch (cfg) {
         case 0: case 1: case 2: case 14: return p.cout_pad % 128 == 0;
-        case 3: case 4: case 5: case 6: return p.cout_pad % 64 == 0;
+        case 3: case 4: case 5: case 6: case 16: return p.cout_pad % 64 == 0;
         case 12: case 13: case 15: {
             const char* e = getenv("VTD_EPI_DIRECT");
             return p.cout_pad % (cfg == 15 ? 256 : 128) == 0 && epi_direct_eligible(p) && !(e && e[0] == '0');
@@ -707,6 +724,7 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
         case 14: return launch_cfg<256, 128, 4, 4, 3>(p, stream);
         case 15: return launch_cfg<256, 256, 2, 4, 2>(p, stream);
+        case 16: return launch_cfg<128, 64, 2, 2, 6>(p, stream);
         case 12: return launch_cfg<208, 128, 2, 4, 3>(p, stream);
         case 13: return launch_cfg<272, 128, 2, 4, 3>(p, stream);
         default: {

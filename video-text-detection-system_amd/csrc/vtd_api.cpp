@@ -1430,7 +1430,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
     if (o.kind == Op::CONV) {
         const ConvOp& c = o.conv;
         static const char* kTile[] = {"256,128,s3", "128,128,s2", "128,128,s3", "256,64,s2", "256,64,s3", "128,64,s2", "128,64,s3",
-                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed", "208,128,s3", "272,128,s3", "256,128,s3,16w", "256,256,s2"};
+                                      "64,256,s2", "128,64,s2,classed", "128,64,s3,classed", "256,64,s2,classed", "256,64,s3,classed", "208,128,s3", "272,128,s3", "256,128,s3,16w", "256,256,s2", "128,64,s6"};
         int cfg = -1;
         if (!d->tuned.empty()) cfg = d->tuned.rbegin()->second[op_index];
         if (cfg == kHeadEntryPairCfg)
@@ -1451,7 +1451,7 @@ int vtd_detector_get_profile(vtd_detector* d, int op_index, char* name, int name
             std::snprintf(name, name_cap, "conv_halo%s 3x3 M/img=%d N=%d K=%d", cfg == kHaloC64Cfg ? "_c64_persistent" : cfg == kHalo64Cfg ? "64" : "",
                           c.ho * c.wo, c.cout, c.K);
         else
-            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 16) ? kTile[cfg] : "default",
+            std::snprintf(name, name_cap, "conv_igemm<%s> M/img=%d N=%d K=%d%s", (cfg >= 0 && cfg < 17) ? kTile[cfg] : "default",
                           c.ho * c.wo, c.cout, c.K, c.plist ? " (lateral+smooth+head conv composed)" : "");
     } else if (o.kind == Op::POOL) {
         std::snprintf(name, name_cap, "maxpool %dx%d/s%d", o.pk[0], o.pk[1], o.pk[2]);
