@@ -69,7 +69,7 @@ def test_table_entries_steer_the_launch_and_invalid_ones_are_ignored(hip, monkey
         # descriptions name the forced tile (the entry was honoured), outputs stay within the fp16 tolerance (the tile shapes
         # share one K walk, so they may even agree bit for bit)
         from vtd_amd.engine import detector_profile
-        forced = {k: (5 if table[k] != 5 else 6) for k in keys if table[k] < 8}
+        forced = {k: (5 if table[k] != 5 else 6) for k in keys if table[k] < 8 or 12 <= table[k] <= 16}   # implicit-GEMM tile ids
         assert len(forced) >= 8
         eng.set_tuning("".join(f"{k} {v}\n" for k, v in forced.items()) + "# a comment line\nconv|bogus|n2 3\n")
         out = eng.forward(x)["probability"].cpu().numpy()
