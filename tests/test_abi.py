@@ -72,3 +72,19 @@ def test_head_entry_half_halo_schedule_is_hazard_free_and_complete():
             assert len(fetches) == 2 * (groups - 1)
             assert [h for _, h in fetches] == [0, 1] * (groups - 1)
             assert all(b[0] - a[0] >= 2 for a, b in zip(fetches, fetches[1:]))   # never two fetches at consecutive step tops
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """libvtd_comm.so (include/vtd_comm.h: vtd_gather over RCCL) builds, loads without a GPU and exports what its header declares."""
+    import __graft_entry__
+    __graft_entry__.build()
+    from vtd_amd import _native_comm
+    text = open(os.path.join(ROOT, "include", "vtd_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(vtd_[a-z0-9_]+)\s*\(", text)))
+    lib = ctypes.CDLL(_native_comm.LIB_PATH)
+    assert len(declared) == 6
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_native_comm.SIGNATURES) == declared
+    _native_comm.load()

@@ -82,3 +82,28 @@ def test_rank_aware_process_video_on_device(hip, tmp_path):
     assert sum(len(fr["detections"]) for fr in r0["results"]) > 50
     assert r0["shard"] == {"rank": 0, "world_size": 2}
     assert r0["summary"]["total_detections"] == want["summary"]["total_detections"]
+
+
+def test_vtd_gather_c_entry_single_rank(hip):
+    """include/vtd_comm.h: unique id -> communicator -> all-gather of a record block on the caller's stream, world size 1 (the only
+    RCCL world one GPU can host: the two-rank tests above run over gloo); the block comes back unchanged and the handle reports
+    its rank / world size."""
+    import ctypes as C
+    import torch
+    from vtd_amd import _native_comm
+    lib = _native_comm.load()
+    ident = (C.c_ubyte * _native_comm.ID_BYTES)()
+    _native_comm.check(lib.vtd_comm_unique_id(ident), "vtd_comm_unique_id")
+    comm = C.c_void_p()
+    _native_comm.check(lib.vtd_comm_create(ident, 0, 1, C.byref(comm)), "vtd_comm_create")
+    try:
+        assert lib.vtd_comm_rank(comm) == 0 and lib.vtd_comm_world_size(comm) == 1
+        rec = torch.randint(-2 ** 31, 2 ** 31 - 1, (32, 64, 16), dtype=torch.int32, device="cuda")
+        out = torch.zeros_like(rec)
+        s = torch.cuda.current_stream()
+        _native_comm.check(lib.vtd_gather(comm, C.c_void_p(rec.data_ptr()), rec.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)), "vtd_gather")
+        s.synchronize()
+        assert torch.equal(out, rec)
+        assert lib.vtd_gather(comm, None, 4, C.c_void_p(out.data_ptr()), None) != 0
+    finally:
+        lib.vtd_comm_destroy(comm)

@@ -45,7 +45,20 @@ def build(force=False, verbose=False):
         raise RuntimeError(f"hipcc failed for {failed}")
     if procs or not os.path.exists(OUT):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT], check=True)
+    if not VARIANT:
+        build_comm(force)
     return OUT
+
+
+def build_comm(force=False):
+    """libvtd_comm.so (include/vtd_comm.h): the detections all-gather over RCCL, a library of its own (links librccl)."""
+    src = os.path.join(HERE, "csrc_comm", "vtd_comm.cpp")
+    out = os.path.join(OUT_DIR, "libvtd_comm.so")
+    hdr = os.path.join(HERE, "..", "include", "vtd_comm.h")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["hipcc", "-O2", "-fPIC", "-std=c++17", "-Wall", "-shared", src, "-o", out, "-L/opt/rocm/lib", "-lrccl",
+                        "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
 
 
 if __name__ == "__main__":
