@@ -318,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
     for (int i = tid; i < 2 * p.nsteps; i += 256) stab[i] = steps[i];
     __syncthreads();
     auto koff_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * s]); };
-    auto desc_of = [&](int s) { return __builtin_amdgcn_readfirstlane(stab[2 * (s < p.nsteps ? s : p.nsteps - 1) + 1]); };
     // fragments of (tap offset, ring stage, half kk).  PMC (SQ_INSTS_VALU / SQ_INSTS_MFMA) put this kernel at 3.7 vector instructions
     // per MFMA -- 8 issue cycles for the MFMA + 15 for VALU against the 16 cycles the MFMA occupies the pipe: the waves were
     // issue-bound, and most of it was address arithmetic of these reads (row = base + tap, row * 128, (row & 6) ^ chunk, shift,

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int SP_PT_ROWS = 7, SP_PT_COLS = 8;         // pooled pixels per tile
-constexpr int SP_CT_ROWS = 15, SP_CT_COLS = 17;       // conv outputs per tile
+constexpr int SP_CT_COLS = 17;                        // conv outputs per tile: 15 rows x 17 columns
 constexpr int SP_PATCH_COLS = 40;                     // input pixels per staged patch row (35 rows used)
 constexpr int SP_PIECES = 12;                         // 1 KB LDS-DMA pieces per patch: 35 rows x 20 units of 16 bytes = 700 units
 constexpr int SP_PATCH_BYTES = SP_PIECES * 1024;      // (the 256th, idle GEMM row reads rows 35, 36: still inside)
