@@ -173,3 +173,19 @@ def test_transformer_recognizer_surface_and_default_pipeline(base, golden_dir, m
     res = pipe.process_single_frame(frame)
     assert len(res["detections"]) >= 3 and all(d["recognition_confidence"] == 0.95 for d in res["detections"])
     json.dumps(res)
+
+
+def test_fused_decoder_qkv_is_bit_identical_to_three_gemms(base, monkeypatch):
+    """The decoder's self-attention q | k | v projections run as one GEMM with three destinations (q, the key-cache row, the value-cache
+    row: ConvParams::seg_cols) on the full trocr-base-printed width.  Same fp16 weights, same K order per output: greedy ids and
+    teacher-forced logits are exactly those of the three separate GEMMs (VTD_TROCR_FUSED_QKV=0)."""
+    eng, sd = base
+    px = torch.stack([otrocr.preprocess(synth.glyph_crop(950 + i), BASE_PRINTED) for i in range(6)])
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VTD_TROCR_FUSED_QKV", mode)
+        ids, _ = eng.generate_pixels(px, max_length=12)
+        _, lg = eng.generate_pixels(px, forced=ids.numpy()[:, :8], want_logits=True, max_length=12)
+        outs[mode] = (ids.numpy().copy(), lg.numpy().copy())
+    assert np.array_equal(outs["1"][0], outs["0"][0])
+    assert np.array_equal(outs["1"][1], outs["0"][1])

@@ -583,7 +583,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-                *(half8*)((half_t*)p.out + (int64_t)(m0 + row) * p.ldc + ch) = hv;
+                if (p.seg_cols > 0) {
+                    const int sg = ch / p.seg_cols;
+                    *(half8*)((half_t*)p.seg_out[sg] + (int64_t)(m0 + row) * p.seg_ldc[sg] + (ch - sg * p.seg_cols)) = hv;
+                } else {
+                    *(half8*)((half_t*)p.out + (int64_t)(m0 + row) * p.ldc + ch) = hv;
+                }
             } else if (p.flags & EPI_OUT_F32) {
                 float* o = (float*)p.out + (int64_t)(m0 + row) * p.ldc + ch;
                 if (ch + 7 < p.cout) {
@@ -692,6 +697,11 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
     if ((p.cout & 7) && !(p.flags & EPI_OUT_F32)) return -1002;
     if ((p.flags & EPI_OUT_F32) && (p.ldc & 3)) return -1003;
     if ((p.flags & EPI_OUT_F16) && ((p.ldc & 7) || (p.cout & 7))) return -1003;
+    if (p.seg_cols) {
+        if (!(p.flags & EPI_OUT_F16) || p.seg_cols < 256 || (p.seg_cols & 255) || p.cout % p.seg_cols || p.cout / p.seg_cols > 3) return -1010;
+        for (int i = 0; i < p.cout / p.seg_cols; ++i)
+            if (!p.seg_out[i] || (p.seg_ldc[i] & 7) || p.seg_ldc[i] < p.seg_cols) return -1010;
+    }
     if ((p.flags & EPI_PIXEL_SHUFFLE) && (p.ps_cout & 7)) return -1004;
     if (p.ho >= 65536 || p.wo >= 32768) return -1005;
     if ((p.flags & EPI_HEAD_FINAL) && (p.cout != 256 || p.cout_pad != 256 || !p.head_w || !p.prob_out)) return -1008;

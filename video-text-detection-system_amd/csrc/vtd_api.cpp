@@ -105,6 +105,9 @@ struct ConvOp {
     int64_t macs_per_image = 0;
     void* out_f32 = nullptr;      // EPI_OUT_F32 destination
     int ldc = 0;
+    int seg_cols = 0;             // EPI_OUT_F16 in column segments (ConvParams::seg_cols)
+    void* seg_out[3] = {nullptr, nullptr, nullptr};
+    int seg_ldc[3] = {0, 0, 0};
     const float* head_w = nullptr;  // EPI_HEAD_FINAL
     float head_b = 0.f;
     // classed dual-source mode (fused FPN top + head entry)
@@ -151,6 +154,8 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
     p.out_hp = c.out.hp; p.out_wp = c.out.wp; p.out_c = c.out.c; p.out_ring = c.out.ring;
     p.res_hp = c.res.hp; p.res_wp = c.res.wp; p.res_ring = c.res.ring; p.res_shift = c.res_shift;
     p.ps_cout = c.ps_cout; p.flags = c.flags; p.ldc = c.ldc;
+    p.seg_cols = c.seg_cols;
+    for (int i = 0; i < 3; ++i) { p.seg_out[i] = c.seg_out[i]; p.seg_ldc[i] = c.seg_ldc[i]; }
     p.head_w = c.head_w; p.head_b = c.head_b; p.prob_out = (float*)c.out_f32;
     if (c.plist) {
         p.plist = c.plist; p.tile_combo = c.tile_combo; p.tiles_per_img = c.tiles_per_img;

@@ -62,6 +62,12 @@ struct ConvParams {
     int flags;
     int dbg;               // timing experiments only (VTD_CONV_DEBUG): 1 = A gather pinned to tap 0, 2 = no A loads, 3 = no loads, 4 = no loop barrier, 5 = no epilogue, 6 = no fragment reads after the first
     int ldc;               // EPI_OUT_F32 row stride
+    // EPI_OUT_F16 in column segments: columns [i * seg_cols, (i + 1) * seg_cols) go to seg_out[i] with row stride seg_ldc[i] (0: one
+    // destination, `out` / `ldc`).  seg_cols is a multiple of every tile width, so a tile has one destination.  The TrOCR decoder's
+    // q | k | v projections run as ONE GEMM that writes q, the key-cache row and the value-cache row.
+    int seg_cols;
+    void* seg_out[3];
+    int seg_ldc[3];
     int epi_direct;        // set by vtd_launch_conv: epilogue straight from the accumulators (conv_igemm.hip)
     uint64_t magic_wo, magic_howo;  // ceil(2^40 / wo), ceil(2^40 / (ho * wo)) for it
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
