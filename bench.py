@@ -142,7 +142,7 @@ def main():
         return dry_run(args, rank, world)
     import numpy as np
     import torch
-    from vtd_amd import synth, weights
+    from vtd_amd._fixtures import synth, weights
     from vtd_amd.engine import DeviceFrames, detector_profile
 
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
@@ -175,6 +175,7 @@ def main():
     os.environ["VTD_MAX_BATCH"] = str(B)
     if args.recognizer == "trocr":
         os.environ.setdefault("VTD_TROCR_MAX_CROPS", "512")
+        os.environ.setdefault("VTD_TROCR_SEEDED", "0")   # explicit opt-in: the architecture on synthetic weights (nothing is fetchable)
     pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64
     pipe.detector.model.load_state_dict(sd)

@@ -124,7 +124,7 @@ def main():
 
     # ---- G1 CRNN logits + taps (conv stack, both LSTM layers) on BN-calibrated, amplified weights: with torch's default
     # init the CRNN ignores its input (round-1 review), so the golden would not discriminate anything
-    from vtd_amd import synth, weights
+    from vtd_amd._fixtures import synth, weights
     from oracle import cstages
     sd = weights.calibrated_crnn_state_dict(11)
     ref_crnn = rec.CRNN(97).eval()

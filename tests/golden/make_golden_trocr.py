@@ -59,7 +59,7 @@ def run(model, x, max_length=50):
 
 def main():
     from oracle import trocr as otrocr
-    from vtd_amd import synth, weights
+    from vtd_amd._fixtures import synth, weights
     from vtd_amd.trocr_spec import BASE_PRINTED, TINY
     torch.set_num_threads(8)
     manifest = {}

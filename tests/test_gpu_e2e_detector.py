@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import pipeline as opipe
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 
 pytestmark = pytest.mark.gpu
 

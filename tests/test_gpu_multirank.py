@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +42,7 @@ _RANK = r"""
 import asyncio, json, os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import torch, torch.distributed as dist
-from vtd_amd import weights
+from vtd_amd._fixtures import weights
 from vtd_amd.pipeline import VideoTextPipeline
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)

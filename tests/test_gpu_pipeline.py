@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pipeline as opipe
 from vtd_amd import nets as mynets
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 
 pytestmark = pytest.mark.gpu
 

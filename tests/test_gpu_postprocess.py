@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import cstages
-from vtd_amd import synth
+from vtd_amd._fixtures import synth
 
 pytestmark = pytest.mark.gpu
 

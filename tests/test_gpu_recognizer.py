@@ -11,7 +11,7 @@ from oracle import cstages
 from oracle import nets as onets
 from oracle import pipeline as opipe
 from vtd_amd import nets as mynets
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 from vtd_amd.vocab import build_vocab, id_to_char_table
 
 pytestmark = pytest.mark.gpu

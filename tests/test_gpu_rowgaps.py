@@ -13,7 +13,7 @@ import torch
 from oracle import nets as onets
 from oracle import pipeline as opipe
 from vtd_amd import nets as mynets
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 
 pytestmark = pytest.mark.gpu
 

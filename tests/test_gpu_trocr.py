@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import trocr as otrocr
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 from vtd_amd.trocr_spec import BASE_PRINTED, TINY
 
 pytestmark = pytest.mark.gpu
@@ -154,8 +154,18 @@ def test_transformer_recognizer_surface_and_default_pipeline(base, golden_dir, m
     from vtd_amd.recognizer import TextRecognizer, TransformerRecognizer
     eng, sd = base
     man = json.load(open(os.path.join(golden_dir, "trocr_manifest.json")))["base"]
+    # no checkpoint on disk and no opt-in: construction raises, as from_pretrained does offline (text_recognizer.py:40-42) --
+    # strings of synthetic weights never reach results by accident
+    monkeypatch.delenv("VTD_TROCR_SEEDED", raising=False)
+    monkeypatch.delenv("VTD_TROCR_CHECKPOINT", raising=False)
+    with pytest.raises(OSError):
+        TextRecognizer(use_transformer=True)
+    with pytest.raises(OSError):
+        VideoTextPipeline(backbone="resnet18")
+    assert TransformerRecognizer("seeded:3").synthetic
+    monkeypatch.setenv("VTD_TROCR_SEEDED", "0")     # the explicit opt-in benches and tests use
     rec = TextRecognizer(use_transformer=True)
-    assert rec.use_transformer and isinstance(rec.model, TransformerRecognizer) and len(rec.vocab) == 97
+    assert rec.use_transformer and isinstance(rec.model, TransformerRecognizer) and len(rec.vocab) == 97 and rec.model.synthetic
     rec.model.load_state_dict(sd)
     crop = synth.glyph_crop(man["rows"][0]["seed"])
     out = rec.recognize(crop)

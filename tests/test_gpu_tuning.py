@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from vtd_amd import nets as mynets
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +21,8 @@ _CHILD = r"""
 import hashlib, json, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import numpy as np, torch
-from vtd_amd import nets as mynets, synth, weights
+from vtd_amd import nets as mynets
+from vtd_amd._fixtures import synth, weights
 from vtd_amd.engine import DetectorEngine, DeviceFrames, RecognizerEngine
 sd = mynets.seeded_state_dict(lambda: mynets.DBNet("resnet18"), seed=5)
 eng = DetectorEngine("resnet18", sd, max_batch=4)

@@ -118,3 +118,28 @@ def test_product_has_no_cpu_fallback_and_overlay_imports():
     from app.ml.models.text_detector import DBNet, TextDetector as T2
     from app.ml.models.text_recognizer import CRNN, TextRecognizer as R2
     assert P2 is VideoTextPipeline and T2 is TextDetector and R2 is TextRecognizer and overlay.DBNet is DBNet and overlay.CRNN is CRNN
+
+
+def test_parameter_containers_deepcopy_and_pickle():
+    """DBNet / CRNN are ordinary modules to their users: EMA copies (copy.deepcopy), whole-model torch.save and spawn pickling
+    must work; the engine lock and the native handle stay behind and are rebuilt by the copy at first use."""
+    import copy
+    import io
+    import pickle
+
+    import torch
+
+    from vtd_amd.nets import CRNN, DBNet
+    for m in (DBNet("resnet18"), CRNN(97)):
+        m.load_state_dict(m.state_dict())                 # a model that has been through the public API (version bumped)
+        dup, rt = copy.deepcopy(m), pickle.loads(pickle.dumps(m))
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        for other in (dup, rt):
+            assert other._engine is None and other._engine_version == -1
+            assert other._engine_lock is not m._engine_lock
+            assert other._version == m._version
+            for (k, a), (k2, b) in zip(m.state_dict().items(), other.state_dict().items()):
+                assert k == k2 and torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+        dup.mark_dirty()
+        assert dup._version == m._version + 1             # the copy's bookkeeping is its own

@@ -53,7 +53,7 @@ def test_state_dict_key_contract(golden_dir):
 def test_g1_crnn_logits_and_lstm_taps(golden_dir):
     """G1: the reference's CRNN on BN-calibrated weights and glyph crops -- logits, conv features and both LSTM layer
     outputs.  The fixture is only worth something if the network looks at its input: checked first."""
-    from vtd_amd import synth, weights
+    from vtd_amd._fixtures import synth, weights
     g = _load(golden_dir, "crnn_g1.npz")
     sd = weights.calibrated_crnn_state_dict(11)
     x = torch.from_numpy(synth.glyph_batch(21, 8))
@@ -74,7 +74,7 @@ def test_g1_crnn_logits_and_lstm_taps(golden_dir):
 def test_g1m_margin_crnn_strings(golden_dir):
     """G1m: margin-carrier weights -- the oracle reproduces the strings the reference's softmax + _decode_prediction gave,
     the fixture is well-posed (top-1 margin) and diverse, and the carrier units sit on their saturated levels."""
-    from vtd_amd import weights
+    from vtd_amd._fixtures import weights
     g = _load(golden_dir, "crnn_g1_margin.npz")
     exp = _manifest(golden_dir)["crnn_g1_margin"]["decoded"]
     sd = weights.margin_crnn_state_dict(11)

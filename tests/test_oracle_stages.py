@@ -6,7 +6,7 @@ import pytest
 from PIL import Image
 
 from oracle import cstages
-from vtd_amd import synth
+from vtd_amd._fixtures import synth
 
 
 @pytest.mark.parametrize("shape", [(720, 1280), (1080, 1920), (480, 640), (640, 640), (300, 500), (1000, 37)])

@@ -10,7 +10,7 @@ import torch
 
 from oracle import cstages
 from oracle import trocr as otrocr
-from vtd_amd import synth, weights
+from vtd_amd._fixtures import synth, weights
 from vtd_amd.trocr_spec import BASE_PRINTED, TINY, hf4_key, hf5_key
 
 

@@ -193,6 +193,44 @@ def test_rank_aware_process_video_equals_single_process(tmp_path):
     assert r0["_progress"] == r1["_progress"] and r0["_progress"][-1][0] in (16, N_VIDEO)
 
 
+def _failing_worker(rank, world, port, out_dir, fail_rank, fail_frame):
+    import time
+    _init(rank, world, port)
+    p = _mock_pipeline()
+    if rank == fail_rank:
+        def boom(frame, threshold=0.5):
+            if int(frame[0, 0, 0]) == fail_frame:
+                raise RuntimeError("injected decode / device failure")
+            return _detect(frame, threshold)
+        p.detector.detect.side_effect = boom
+    t0 = time.time()
+    out = asyncio.run(p.process_video("clip.npy", out_dir))
+    out["_seconds"] = time.time() - t0
+    json.dump(out, open(os.path.join(out_dir, f"fail_rank{rank}.json"), "w"))
+    dist.barrier()    # both ranks are still alive and in step after the abort
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_loop_together(tmp_path):
+    """A rank whose loop raises (here: detect on frame 9, in the third round) tells its peers through the error flag of the next
+    capacity all_reduce: every rank returns the reference's 'failed' dict within seconds, nobody waits for the backend timeout
+    (30 min on gloo), and the process group is still usable afterwards.  Same when the failure hits in the very last round."""
+    for fail_rank, fail_frame in ((1, 9), (0, 22)):
+        mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path), fail_rank, fail_frame), nprocs=2, join=True)
+        for rank in range(2):
+            out = json.load(open(tmp_path / f"fail_rank{rank}.json"))
+            assert out["status"] == "failed" and out["results"] == [] and out["_seconds"] < 60, out
+            assert ("injected" in out["error"]) == (rank == fail_rank)
+            assert ("peer rank failed" in out["error"]) == (rank != fail_rank)
+
+
+def test_every_rank_returns_rank0_summary(tmp_path):
+    mp.spawn(_video_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = json.load(open(tmp_path / "video_rank0.json"))
+    r1 = json.load(open(tmp_path / "video_rank1.json"))
+    assert r1["summary"] == r0["summary"] and r0["summary"]["total_detections"] > 0
+
+
 # ---- kernel-selection tables travel from rank 0 to every rank -----------------------------------------------------------
 class _FakeEngine:
     def __init__(self, text):

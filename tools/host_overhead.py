@@ -6,7 +6,8 @@ sys.path[:0] = [os.path.join(ROOT, "video-text-detection-system_amd"), ROOT]
 import ctypes as C
 import numpy as np
 import torch
-from vtd_amd import synth, weights, _native, nets as mynets
+from vtd_amd import _native, nets as mynets
+from vtd_amd._fixtures import synth, weights
 from vtd_amd.engine import DetectorEngine, DeviceFrames, PostProcessor
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -16,13 +16,16 @@ if EXTRA and not VARIANT:
 OUT = os.path.join(OUT_DIR, f"libvtd_hip_{VARIANT}.so" if VARIANT else "libvtd_hip.so")
 OBJ_DIR = os.path.join(HERE, f"build_{VARIANT}" if VARIANT else "build")
 
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + EXTRA
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + CSRC] + EXTRA
 # the post-process geometry replays float32 arithmetic in a fixed order: no fused multiply-add there
 PER_FILE = {"postprocess.hip": ["-ffp-contract=off"]}
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+    src = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))
+    if "-DVTD_EXPERIMENTAL_CANDIDATES" in EXTRA:   # measured losing kernel candidates: instrumented builds only, never the product library
+        src += glob.glob(os.path.join(CSRC, "experimental", "*.hip"))
+    return sorted(src)
 
 
 def build(force=False, verbose=False):
@@ -46,7 +49,11 @@ def build(force=False, verbose=False):
     if procs or not os.path.exists(OUT):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT], check=True)
     if not VARIANT:
-        build_comm(force)
+        try:   # the compute library carries no communication dependency: a host without RCCL still gets libvtd_hip.so
+            build_comm(force)
+        except (subprocess.CalledProcessError, OSError) as e:
+            print(f"build_native: libvtd_comm.so not built ({e}); vtd_gather (include/vtd_comm.h) is unavailable, "
+                  "torch.distributed remains the product's collective path", file=sys.stderr)
     return OUT
 
 
@@ -56,8 +63,10 @@ def build_comm(force=False):
     out = os.path.join(OUT_DIR, "libvtd_comm.so")
     hdr = os.path.join(HERE, "..", "include", "vtd_comm.h")
     if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.run(["hipcc", "-O2", "-fPIC", "-std=c++17", "-Wall", "-shared", src, "-o", out, "-L/opt/rocm/lib", "-lrccl",
-                        "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
+        libdir = os.path.join(rocm, "lib")
+        subprocess.run(["hipcc", "-O2", "-fPIC", "-std=c++17", "-Wall", "-shared", src, "-o", out, "-I" + os.path.join(rocm, "include"),
+                        "-L" + libdir, "-lrccl", "-Wl,-rpath," + libdir], check=True)
     return out
 
 

@@ -27,10 +27,14 @@ void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
 int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
 int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream);
+#ifdef VTD_EXPERIMENTAL_CANDIDATES
+// csrc/experimental/: measured, parity-green, LOSING candidates of the composed head entry.  They are not part of the
+// product library: only an instrumented build (VTD_LIB_VARIANT=<tag> VTD_EXTRA_HIPCC_FLAGS=-DVTD_EXPERIMENTAL_CANDIDATES) carries them.
 int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out);
 int vtd_launch_head_entry_half(const ConvParams& c, const int* sched_dev, int nsteps, hipStream_t stream);
 int vtd_head_entry_pair_tables(int py, int px, int c2ch, int* half_steps, int* plan);
 int vtd_launch_head_entry_pair(const ConvParams& c, const int* half_steps_dev, const int* plan_dev, int nh, hipStream_t stream);
+#endif
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out);
 bool vtd_conv_halo_c64_supported(const ConvParams& c, int tw);
 int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream);
@@ -206,6 +210,7 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
     ConvParams p;
     fill_conv_params(c, n, p);
     if (prob_out) p.prob_out = prob_out;
+#ifdef VTD_EXPERIMENTAL_CANDIDATES
     if (cfg == kHeadEntryPairCfg) {
         if (!c.hp_half_steps || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_pair(p, c.hp_half_steps, c.hp_plan, c.hp_nh, s);
@@ -214,6 +219,9 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
         if (!c.hh_sched || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_half(p, c.hh_sched, c.he_nsteps, s);
     }
+#else
+    if (cfg == kHeadEntryPairCfg || cfg == kHeadEntryHalfCfg) return ERR_GEOMETRY;  // candidates of the instrumented build only
+#endif
     if (cfg == kHeadEntryHaloCfg || cfg == kHeadEntryHalo256Cfg) {  // interior classes only; border tiles = the next graph slot
         if (!c.he_steps || !c.tile_combo_border) return ERR_GEOMETRY;
         return vtd_launch_head_entry_halo(p, c.he_steps, c.he_nsteps, cfg == kHeadEntryHalo256Cfg ? 1 : 0, s);
@@ -907,6 +915,7 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
         if ((rc = upload(d->arena, steps.data(), steps.size() * sizeof(int), &st))) return rc;
         if ((rc = upload(d->arena, border.data(), border.size() * sizeof(int), &bd))) return rc;
         op.he_steps = (const int*)st; op.he_nsteps = nsteps;
+#ifdef VTD_EXPERIMENTAL_CANDIDATES
         if (25 * c2.c + 9 * 256 <= 0xffff) {  // half-halo kernel: schedules derived from the same step tables (16-bit weight column offsets)
             std::vector<int> sched((size_t)4 * nsteps * 4);
             bool ok = true;
@@ -918,7 +927,9 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
                 op.hh_sched = (const int*)sd;
             }
         }
+#endif
         op.tile_combo_border = (const int*)bd; op.tiles_border = (int)border.size();
+#ifdef VTD_EXPERIMENTAL_CANDIDATES
         {   // pair kernel (head_entry_pair.hip): half-step tables + halo prefetch plans; only where its LDS budget holds (C2 of 64 channels)
             const int nh = 25 * (c2.c / 32) + 72;
             if (c2.c == 64) {
@@ -934,6 +945,7 @@ static int build_classed_head_entry(vtd_detector* d, ConvOp& op, const TensorDes
                 }
             }
         }
+#endif
     }
     op.bias = (float*)bt;  // first class doubles as the (unused) flat bias
     op.bias_tab = (const float*)bt;
@@ -1245,7 +1257,13 @@ static int get_pre_tables(vtd_detector* d, int H, int W, PreTables& out) {
 
 extern "C" {
 
-const char* vtd_version(void) { return "vtd_hip 0.1 (gfx950)"; }
+const char* vtd_version(void) {
+#ifdef VTD_EXPERIMENTAL_CANDIDATES
+    return "vtd_hip 0.3 (gfx950) +experimental";
+#else
+    return "vtd_hip 0.3 (gfx950)";
+#endif
+}
 
 const char* vtd_strerror(int code) {
     static thread_local char buf[128];

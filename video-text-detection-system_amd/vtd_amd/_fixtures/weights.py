@@ -19,7 +19,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import nets
+from .. import nets
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
@@ -315,7 +315,7 @@ def margin_crnn_state_dict(seed=0, vocab_size=97, cls_gain=3.0):
 # embeddings carry the state, sublayers perturb it (std 0.01), cross-attention output is amplified (x2) so the image
 # decides without drowning the previous token, the output projection is untied and its <eos> row is scaled so sequences end after ~10 tokens.
 def trocr_state_dict(spec=None, seed=0, w_std=0.01, tok_std=1.0, pos_std=0.3, out_std=0.03, cross_gain=2.0, eos_gain=3.4, cross_sharp=1.0):
-    from .trocr_spec import BASE_PRINTED
+    from ..trocr_spec import BASE_PRINTED
     s = spec or BASE_PRINTED
     g = torch.Generator().manual_seed(1000 + seed)
 

@@ -36,9 +36,12 @@ class _Tunable:
     _kind = None
 
     def set_tuning(self, text):
+        """Replaces table entries; under the engine lock, so a forward / generate in another thread never sees its resolved launch
+        slots cleared half way."""
         if text:
             fn = getattr(self.lib, f"vtd_{self._kind}_set_tuning")
-            _native.check(fn(self.handle, text.encode()), f"vtd_{self._kind}_set_tuning")
+            with self.lock:
+                _native.check(fn(self.handle, text.encode()), f"vtd_{self._kind}_set_tuning")
 
     def tuning_text(self):
         fn = getattr(self.lib, f"vtd_{self._kind}_get_tuning")

@@ -110,7 +110,51 @@ class DBHead(nn.Module):
         self.threshold_head = _db_branch(in_channels)
 
 
-class DBNet(nn.Module):
+class _EngineOwner:
+    """Engine bookkeeping shared by DBNet and CRNN.  The lock and the native handle are process-local: they are left out of
+    pickles and deep copies (``copy.deepcopy(model)``, ``torch.save(model)``, multiprocessing spawn) and rebuilt on demand, so a
+    copy packs its own engine from its own parameters at first use."""
+
+    def _init_engine_state(self):
+        self._engine = None
+        self._engine_version = -1
+        self._version = 0
+        self._engine_lock = threading.Lock()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_engine_version"] = -1
+        state.pop("_engine_lock", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._engine = None
+        self._engine_version = -1
+        self._engine_lock = threading.Lock()
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engine_lock = threading.Lock()
+        return new
+
+    # any in-place parameter update through the public API invalidates the packed copy
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        try:
+            return super().load_state_dict(state_dict, strict=strict, **kw)
+        finally:   # torch copies the matching tensors before it raises on a mismatch: the packed copy is stale either way
+            self._version += 1
+
+    def mark_dirty(self):
+        self._version += 1
+
+
+class DBNet(_EngineOwner, nn.Module):
     """DBNet detector network (text_detector.py:12-29), compute on the HIP engine.
 
     ``forward(x)`` accepts what the reference's ``TextDetector`` feeds it -- a
@@ -130,20 +174,7 @@ class DBNet(nn.Module):
         # the reference computes the threshold map and never reads it at inference
         # (text_detector.py:128); off by default, same kernels when switched on
         self.compute_threshold = compute_threshold
-        self._engine = None
-        self._engine_version = -1
-        self._version = 0
-        self._engine_lock = threading.Lock()
-
-    # any in-place parameter update through the public API invalidates the packed copy
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        try:
-            return super().load_state_dict(state_dict, strict=strict, **kw)
-        finally:   # torch copies the matching tensors before it raises on a mismatch: the packed copy is stale either way
-            self._version += 1
-
-    def mark_dirty(self):
-        self._version += 1
+        self._init_engine_state()
 
     def engine(self):
         """The native engine for the current parameters, built once under a lock (detect() is entered from four pool threads,
@@ -165,7 +196,7 @@ class DBNet(nn.Module):
         return self.engine().forward(x, want_threshold=self.compute_threshold)
 
 
-class CRNN(nn.Module):
+class CRNN(_EngineOwner, nn.Module):
     """CRNN recogniser parameters (text_recognizer.py:12-37): 7 conv(+BN+ReLU) with the four
     pools, 2-layer bidirectional LSTM(512->256), Linear(512->vocab).  ``forward`` takes
     ``[B,3,32,128]`` float (BGR/255, text_recognizer.py:118-119) and returns ``[B,31,V]``
@@ -189,19 +220,7 @@ class CRNN(nn.Module):
         self.rnn = nn.LSTM(512, hidden_size, num_layers, batch_first=True, bidirectional=True)
         self.classifier = nn.Linear(hidden_size * 2, vocab_size)
         self.vocab_size = vocab_size
-        self._engine = None
-        self._engine_version = -1
-        self._version = 0
-        self._engine_lock = threading.Lock()
-
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        try:
-            return super().load_state_dict(state_dict, strict=strict, **kw)
-        finally:   # torch copies the matching tensors before it raises on a mismatch: the packed copy is stale either way
-            self._version += 1
-
-    def mark_dirty(self):
-        self._version += 1
+        self._init_engine_state()
 
     def engine(self):
         from . import engine as _e

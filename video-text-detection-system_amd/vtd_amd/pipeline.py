@@ -10,7 +10,9 @@ crops one at a time; here a batch is ONE device pass -- fused preprocess -> DBNe
 then every crop of the batch through crop/resize -> CRNN -> CTC decode -- with frames, maps, boxes and crops
 resident in HBM.  The reference-shaped route is kept and taken whenever the test seams are in use
 (``detector.detect`` / ``recognizer.recognize`` patched or replaced, tests/test_models.py:115-141,
-tests/test_integration.py:54-79 of the reference), or when frames of a batch differ in size.
+tests/test_integration.py:54-79 of the reference) or a frame is not an HxWx3 uint8 array.  Frames of different sizes in one
+batch (the reference takes any mix, pipeliine.py:96-101; BASELINE configs[4] alternates 720p / 1080p) stay on the device path:
+the batch is grouped by frame shape, each group is one device pass, and the results are re-interleaved in frame order.
 """
 import asyncio
 import os
@@ -61,7 +63,11 @@ class VideoTextPipeline:
         only its own frames through its device pipeline, and once per round of W x batch_size frames the ranks exchange
         their finished results in ONE all_gather of a padded block (vtd_amd/shard.py, RCCL on its own stream).  Rank 0
         returns the merged result ordered by frame number -- identical to the single-GPU result; the other ranks return
-        the same summary / video_info with an empty 'results' list."""
+        rank 0's summary (broadcast at the end) and video_info with an empty 'results' list.  Every rank reads the whole clip
+        from its frame source and keeps only its own frames (the source decides whether skipped frames cost a decode).  A rank
+        that fails tells the others at their next sequence point (shard.ResultGather: error flag in the capacity
+        all_reduce), so all ranks return 'failed' together instead of waiting in a collective."""
+        gather = None
         try:
             from . import shard
             start_time = time.time()
@@ -72,7 +78,7 @@ class VideoTextPipeline:
             frame_count = 0
             total_frames = video_info.get("frame_count", 0)
             pending_frames, pending_info = [], []
-            world, rank, gather = 1, 0, None
+            world, rank = 1, 0
             if shard.is_distributed() and os.environ.get("VTD_SHARD_VIDEO", "1") != "0":
                 import torch.distributed as dist
                 world, rank = dist.get_world_size(), dist.get_rank()
@@ -82,9 +88,9 @@ class VideoTextPipeline:
             loop = asyncio.get_event_loop()
 
             async def flush(last=False):
-                # Batches of equally sized frames ride the three-deep device pipeline (upload stream -> detector -> post-process /
-                # recogniser streams, see _pipeline_push): results come back one or two batches later, in frame order.  Anything
-                # else drains the pipeline first and takes the reference-shaped route.
+                # Batches of uint8 frames ride the three-deep device pipeline (upload stream -> detector -> post-process /
+                # recogniser streams, see _pipeline_push), one device pass per frame size: results come back one or two batches
+                # later, in frame order.  Anything else drains the pipeline first and takes the reference-shaped route.
                 nonlocal frame_count, seen
                 done = []
                 if pending_frames:
@@ -122,14 +128,21 @@ class VideoTextPipeline:
             if gather is not None:
                 all_results.sort(key=lambda fr: fr["frame_number"])
             processing_time = time.time() - start_time
-            out = {"status": "success", "results": all_results,
-                   "summary": self._generate_summary(all_results, processing_time, frame_count), "video_info": video_info}
+            summary = self._generate_summary(all_results, processing_time, frame_count)
+            if gather is not None:   # last sequence point: nobody failed -> every rank returns rank 0's summary
+                summary = await loop.run_in_executor(self.executor, gather.finish, summary if rank == 0 else None)
+            out = {"status": "success", "results": all_results, "summary": summary, "video_info": video_info}
             if gather is not None:
                 out["shard"] = {"rank": rank, "world_size": world}
             return out
         except Exception as e:
             logger.error(f"Video processing failed: {e}")
             self._abandon_pipeline()
+            if gather is not None and not gather.closed:
+                try:   # tell the peers at their next sequence point (they return 'failed' too)
+                    gather.abort()
+                except Exception as e2:
+                    logger.error(f"Could not notify the peer ranks: {e2}")
             return {"status": "failed", "error": str(e), "results": []}
 
     def _bind_device(self):
@@ -140,8 +153,27 @@ class VideoTextPipeline:
             torch.cuda.set_device(dev)
 
     # ---- device pipeline of the video loop: batch i uploads and detects while batch i-1 is recognised and batch i-2 is collected
-    def _pipeline_push(self, frames, frame_info) -> List[Dict]:
+    @staticmethod
+    def _shape_groups(frames):
+        """[(positions of the frames of one shape)] in order of first appearance: one device pass per group."""
+        groups = {}
+        for pos, f in enumerate(frames):
+            groups.setdefault(tuple(f.shape), []).append(pos)
+        return list(groups.values())
+
+    def _stage(self, chunk):
+        """A group's frames as one resident batch: host arrays go through a pinned staging buffer and the upload stream (the
+        copy overlaps the previous batch's compute); frames that already live in HBM are stacked there."""
         from .engine import PINNED, DeviceFrames
+        if torch.is_tensor(chunk[0]):
+            return DeviceFrames(torch.stack(list(chunk))), None
+        host = PINNED.take((len(chunk),) + tuple(chunk[0].shape), torch.uint8)  # pinned staging: the copy is truly asynchronous
+        staged = host.numpy()
+        for i, f in enumerate(chunk):
+            staged[i] = f
+        return DeviceFrames(host, stream=self._upload), host
+
+    def _pipeline_push(self, frames, frame_info) -> List[Dict]:
         self._bind_device()
         if getattr(self, "_inflight", None) is None:
             self._inflight = []
@@ -149,26 +181,35 @@ class VideoTextPipeline:
             self._upload = torch.cuda.Stream()
         out = []
         cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
-        for start in range(0, len(frames), cap):
-            chunk, info = frames[start:start + cap], frame_info[start:start + cap]
-            host = PINNED.take((len(chunk),) + tuple(chunk[0].shape), torch.uint8)  # pinned staging: the copy is truly asynchronous
-            staged = host.numpy()
-            for i, f in enumerate(chunk):
-                staged[i] = f
-            try:
-                job = self.submit_detection(DeviceFrames(host, stream=self._upload))
-            except Exception as e:
-                # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
-                # that cannot be enqueued degrades to empty detections for its frames, the video goes on
-                logger.error(f"Detection failed: {e}")
-                job = {"failed": True}
-            job["info"], job["host"] = info, host
-            self._inflight.append(job)
-            if len(self._inflight) >= 2:
-                self._try_recognition(self._inflight[-2])
-            if len(self._inflight) >= 3:
-                out += self._retire(self._inflight.pop(0))
+        # results of one pushed batch are handed back together, in frame order, once its last group retires (jobs retire in
+        # submission order, so batches stay in order too)
+        token = {"left": 0, "parts": []}
+        for positions in self._shape_groups(frames):
+            for start in range(0, len(positions), cap):
+                idx = positions[start:start + cap]
+                info = [frame_info[i] for i in idx]
+                host = None
+                try:
+                    batch, host = self._stage([frames[i] for i in idx])
+                    job = self.submit_detection(batch)
+                except Exception as e:
+                    # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
+                    # that cannot be enqueued degrades to empty detections for its frames, the video goes on
+                    logger.error(f"Detection failed: {e}")
+                    job = {"failed": True}
+                job.update(info=info, host=host, token=token, pos=idx)
+                token["left"] += 1
+                self._route_count("device", len(idx))
+                self._inflight.append(job)
+                if len(self._inflight) >= 2:
+                    self._try_recognition(self._inflight[-2])
+                if len(self._inflight) >= 3:
+                    out += self._retire(self._inflight.pop(0))
         return out
+
+    def _route_count(self, route, n):
+        counts = self.__dict__.setdefault("route_counts", {"device": 0, "reference": 0})
+        counts[route] += n
 
     def _try_recognition(self, job):
         if "rec" in job or job.get("failed"):
@@ -190,8 +231,14 @@ class VideoTextPipeline:
                 logger.error(f"Batch collection failed: {e}")
         if res is None:
             res = [{"frame_number": num, "timestamp": ts, "detections": []} for num, ts in job["info"]]
-        PINNED.release(job["host"])
-        return res
+        if job.get("host") is not None:
+            PINNED.release(job["host"])
+        token = job["token"]
+        token["parts"] += zip(job["pos"], res)
+        token["left"] -= 1
+        if token["left"]:
+            return []
+        return [r for _, r in sorted(token["parts"], key=lambda t: t[0])]
 
     def _pipeline_drain(self) -> List[Dict]:
         self._bind_device()
@@ -209,6 +256,8 @@ class VideoTextPipeline:
 
     # ---------------------------------------------------------------------------------- batches
     def _fast_path_ok(self, frames) -> bool:
+        """The device path takes any mix of frame sizes; only the test seams (detect / recognize patched or replaced) and frames
+        that are not HxWx3 uint8 arrays (or resident uint8 tensors) go the reference-shaped way."""
         try:
             from .detector import TextDetector
             from .recognizer import TextRecognizer
@@ -218,9 +267,13 @@ class VideoTextPipeline:
             return False
         if not frames:
             return False
-        shape = getattr(frames[0], "shape", None)
-        return (shape is not None and len(shape) == 3 and shape[2] == 3
-                and all(getattr(f, "shape", None) == shape and getattr(f, "dtype", None) == np.uint8 for f in frames))
+
+        def ok(f):
+            shape = getattr(f, "shape", None)
+            if shape is None or len(shape) != 3 or shape[2] != 3 or shape[0] <= 0 or shape[1] <= 0:
+                return False
+            return f.dtype == torch.uint8 and f.is_cuda if torch.is_tensor(f) else getattr(f, "dtype", None) == np.uint8
+        return all(ok(f) for f in frames)
 
     def process_device_batch(self, batch, frame_info=None) -> List[Dict]:
         """The batched device pass on frames that are already resident in HBM (a ``DeviceFrames``): fused
@@ -302,18 +355,23 @@ class VideoTextPipeline:
     def _batched_device_pass(self, frames, frame_info) -> List[Dict]:
         from .engine import DeviceFrames
         self._bind_device()
-        results = []
+        parts = []
         cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
-        for start in range(0, len(frames), cap):
-            chunk = frames[start:start + cap]
-            results += self.process_device_batch(DeviceFrames(chunk), frame_info[start:start + cap])
-        return results
+        for positions in self._shape_groups(frames):   # one device pass per frame size, results back in frame order
+            for start in range(0, len(positions), cap):
+                idx = positions[start:start + cap]
+                chunk = [frames[i] for i in idx]
+                batch = DeviceFrames(torch.stack(chunk) if torch.is_tensor(chunk[0]) else chunk)
+                parts += zip(idx, self.process_device_batch(batch, [frame_info[i] for i in idx]))
+                self._route_count("device", len(idx))
+        return [r for _, r in sorted(parts, key=lambda t: t[0])]
 
     async def _process_frame_batch(self, frames: List[np.ndarray], frame_info: List[Tuple], output_dir: str) -> List[Dict]:
         loop = asyncio.get_event_loop()
         if self._fast_path_ok(frames):
             return await loop.run_in_executor(self.executor, self._batched_device_pass, list(frames), list(frame_info))
         # reference-shaped route (pipeliine.py:96-141): N=1 detect per frame on the pool, one recognize per crop
+        self._route_count("reference", len(frames))
         tasks = [loop.run_in_executor(self.executor, self.detector.detect, frame, self.confidence_threshold) for frame in frames]
         batch_detections = await asyncio.gather(*tasks)
         results = []

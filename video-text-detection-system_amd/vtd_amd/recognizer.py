@@ -38,11 +38,19 @@ def _bytes_to_unicode():
 class TransformerRecognizer:
     """``TransformerRecognizer`` of the reference (text_recognizer.py:39-69).
 
-    ``model_name``: the reference downloads ``microsoft/trocr-base-printed`` from the hub.  Nothing can be fetched here, so: a
-    local directory holding the checkpoint (``model.safetensors`` or ``pytorch_model.bin`` = the state dict of
-    ``VisionEncoderDecoderModel``, optionally ``vocab.json`` for the byte-level BPE decode) is loaded; any other name yields the
-    trocr-base-printed architecture on deterministic seeded weights (logged) -- the same repair the detector applies to
-    ``pretrained=True``.  Without ``vocab.json`` token ids are rendered as ``<id>`` markers (tokenizer parity is unpinned)."""
+    ``model_name``: the reference hands ``microsoft/trocr-base-printed`` to ``from_pretrained``, which downloads it or raises.
+    Nothing can be fetched here, so a checkpoint has to be on disk:
+
+    * a local directory (``model_name`` itself, or ``$VTD_TROCR_CHECKPOINT`` when ``model_name`` is a hub name) holding
+      ``model.safetensors`` or ``pytorch_model.bin`` (= the state dict of ``VisionEncoderDecoderModel``) and optionally
+      ``vocab.json`` for the byte-level BPE decode;
+    * ``"seeded:<n>"`` (or ``$VTD_TROCR_SEEDED=<n>`` for a hub name): the trocr-base-printed ARCHITECTURE on deterministic
+      synthetic weights -- an explicit opt-in for benches and tests (``self.synthetic`` is then True and the texts are
+      ``<id>`` markers: they are token ids of random weights, not recognised text);
+    * anything else raises ``OSError`` at construction, as ``from_pretrained`` does offline: synthetic strings never flow into
+      results, exports or the database by accident.
+
+    Parity with the real checkpoint and its tokenizer is unpinned (neither can be fetched)."""
 
     SPECIAL = (0, 1, 2, 3)  # <s>, <pad>, </s>, <unk>: dropped by batch_decode(skip_special_tokens=True)
 
@@ -52,17 +60,27 @@ class TransformerRecognizer:
         self.spec = spec or BASE_PRINTED
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.model_name = model_name
+        self.synthetic = False
+        self._seed = 0
         self._max_crops = max_crops
         self._sd = None
         self._engine = None
         self._lock = threading.Lock()
         self._id2tok = None
         self._byte_decoder = {v: k for k, v in _bytes_to_unicode().items()}
-        if model_name and os.path.isdir(model_name):
-            self._load_directory(model_name)
+        name = model_name or ""
+        local = name if os.path.isdir(name) else os.environ.get("VTD_TROCR_CHECKPOINT", "")
+        seeded = name[len("seeded:"):] if name.startswith("seeded:") else os.environ.get("VTD_TROCR_SEEDED", "")
+        if name.startswith("seeded:") or (not (local and os.path.isdir(local)) and seeded != ""):
+            self.synthetic, self._seed = True, int(seeded or 0)
+            logger.warning(f"TrOCR: trocr-base-printed architecture on SYNTHETIC weights (seed {self._seed}); "
+                           "outputs are token-id markers, not recognised text")
+        elif local and os.path.isdir(local):
+            self._load_directory(local)
         else:
-            logger.warning(f"TrOCR checkpoint {model_name!r} is not a local directory and cannot be fetched: "
-                           "running the trocr-base-printed architecture on seeded weights")
+            raise OSError(f"TrOCR checkpoint {model_name!r} is not a local directory and nothing can be downloaded here: pass a "
+                          "directory with model.safetensors / pytorch_model.bin (or set VTD_TROCR_CHECKPOINT), or opt into "
+                          "synthetic weights with model_name='seeded:<n>' / VTD_TROCR_SEEDED=<n>")
 
     def _load_directory(self, path):
         st, pt = os.path.join(path, "model.safetensors"), os.path.join(path, "pytorch_model.bin")
@@ -83,11 +101,11 @@ class TransformerRecognizer:
             self._engine = None
 
     def engine(self):
-        from . import weights
+        from ._fixtures import weights
         from .engine import TrOCREngine
         with self._lock:
             if self._engine is None:
-                sd = self._sd if self._sd is not None else weights.trocr_state_dict(self.spec, seed=0)
+                sd = self._sd if self._sd is not None else weights.trocr_state_dict(self.spec, seed=self._seed)
                 self._engine = TrOCREngine(self.spec, sd, self._max_crops)
                 self._sd = None  # the engine holds the packed copy
             return self._engine

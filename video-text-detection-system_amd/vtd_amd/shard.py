@@ -152,11 +152,20 @@ def required_caps(results):
     return det, txt
 
 
+class ShardAbort(RuntimeError):
+    """A peer rank reported a failure at a sequence point: every rank leaves the video loop together."""
+
+
 class ResultGather:
     """One all_gather of a result block per round of W x batch_size frames, asynchronous on its own stream; blocks are
     turned back into dicts when the round is retired (one round later, so the collective overlaps the next round's
     compute).  Capacities are agreed first with a tiny all_reduce(MAX), so no frame is ever truncated (the reference has
-    no cap on detections per frame)."""
+    no cap on detections per frame).
+
+    Failure protocol: every sequence point (``submit``, ``finish``, ``abort``) opens with the SAME 4-int all_reduce(MAX)
+    whose last slot is an error flag.  A rank that fails anywhere in its loop calls ``abort()`` -- one such all_reduce with
+    the flag raised -- and leaves; the peers meet it at their next sequence point, see the flag and raise ``ShardAbort``
+    instead of entering the all_gather, so nobody is left waiting in a collective until the backend's timeout."""
 
     def __init__(self, group=None):
         self.group = group
@@ -165,18 +174,32 @@ class ResultGather:
         self.device = comm_device()
         self.stream = torch.cuda.Stream() if self.device.type == "cuda" else None
         self.pending = []
+        self.closed = False
+
+    def _agree(self, need):
+        """all_reduce(MAX) of (frames, detections, text length, error flag); raises ShardAbort when any rank raised the flag."""
+        caps = torch.tensor(need, dtype=torch.int32).to(self.device)
+        dist.all_reduce(caps, op=dist.ReduceOp.MAX, group=self.group)
+        frames, max_det, text_cap, flag = (int(v) for v in caps.cpu().tolist())   # small sync: the agreed capacities
+        if flag:
+            self.closed = True
+            raise ShardAbort("a peer rank failed; leaving the sharded video loop on every rank")
+        return frames, max_det, text_cap
 
     def submit(self, results):
         """results: the per-frame dicts this rank finished since the last round (possibly none).  Every rank calls this
         once per round, in the same order."""
-        need = torch.tensor((len(results),) + required_caps(results), dtype=torch.int32)
+        # packed to this rank's own needs BEFORE the first collective: whatever can raise here raises while the peers can
+        # still be told (abort); between the all_reduce and the all_gather nothing can fail any more
+        own_det, own_txt = required_caps(results)
+        own = pack_results(results, max(len(results), 1), max(own_det, 1), max(own_txt, 1))
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
         with ctx:
-            caps = need.to(self.device)
-            dist.all_reduce(caps, op=dist.ReduceOp.MAX, group=self.group)
-            frames, max_det, text_cap = (int(v) for v in caps.cpu().tolist())   # small sync: the agreed capacities
+            frames, max_det, text_cap = self._agree((len(results), own_det, own_txt, 0))
             frames, max_det, text_cap = max(frames, 1), _round_up(max(max_det, 1), 8), _round_up(max(text_cap, 1), 16)
-            local = torch.from_numpy(pack_results(results, frames, max_det, text_cap))
+            blk = np.zeros(block_shape(frames, max_det, text_cap), np.int32)
+            blk[:own.shape[0], :own.shape[1], :own.shape[2]] = own
+            local = torch.from_numpy(blk)
             if self.device.type == "cuda":
                 local = local.pin_memory().to(self.device, non_blocking=True)
             out = torch.empty((self.world,) + tuple(local.shape), dtype=torch.int32, device=self.device)
@@ -187,6 +210,28 @@ class ResultGather:
                 ev = torch.cuda.Event()
                 ev.record()
         self.pending.append((host, ev, local, out))
+
+    def abort(self):
+        """This rank failed: raise the flag at the peers' next sequence point (no-op once a peer's flag has been seen or the
+        loop has finished -- nobody is waiting then)."""
+        if self.closed:
+            return
+        self.closed = True
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            caps = torch.tensor((0, 0, 0, 1), dtype=torch.int32).to(self.device)
+            dist.all_reduce(caps, op=dist.ReduceOp.MAX, group=self.group)
+
+    def finish(self, payload=None, src=0):
+        """Last sequence point: all ranks agree that nobody failed, then rank `src`'s `payload` (the summary of the merged
+        result) is broadcast so every rank returns the same one."""
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            self._agree((0, 0, 0, 0))
+            box = [payload if self.rank == src else None]
+            dist.broadcast_object_list(box, src=src, group=self.group)
+        self.closed = True
+        return box[0]
 
     def retire(self, keep_last=0):
         """Results of every finished round except the newest `keep_last`, ordered by frame number inside a round."""
