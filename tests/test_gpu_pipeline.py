@@ -63,16 +63,21 @@ def test_frame_batch_fast_path_matches_oracle(pipeline):
     assert len(texts) >= 20 and len(set(texts)) >= 4 and all(texts)   # the strings carry information
 
 
-def test_single_frame_and_mixed_sizes_take_the_reference_shaped_route(pipeline):
+def test_single_frame_route_and_mixed_sizes_on_the_device_path(pipeline):
     p, det_sd, rec_sd = pipeline
     frame = synth.text_frame(7, 1080, 1920)[0]
     got = p.process_single_frame(frame)
     exp = opipe.process_single_frame(frame, det_sd, "resnet18", rec_sd, 0.5)
     _same(got["detections"], exp["detections"], rec_sd, frame)
     assert all("polygon" not in d for d in got["detections"])
-    mixed = [synth.text_frame(1, 720, 1280)[0], synth.text_frame(2, 480, 640)[0]]
-    assert not p._fast_path_ok(mixed)
-    out = asyncio.run(p._process_frame_batch(mixed, [(0, 0.0), (1, 0.1)], "/tmp"))
+    # frames of different sizes in one batch (the reference takes any mix, pipeliine.py:96-101): grouped by shape, one device pass
+    # per group, results back in frame order; only non-uint8 / non-HxWx3 frames leave the device path
+    mixed = [synth.text_frame(1, 720, 1280)[0], synth.text_frame(2, 480, 640)[0], synth.text_frame(3, 720, 1280)[0]]
+    assert p._fast_path_ok(mixed)
+    assert not p._fast_path_ok([mixed[0], mixed[1].astype(np.float32)]) and not p._fast_path_ok([mixed[0][..., 0]])
+    p.route_counts = {"device": 0, "reference": 0}
+    out = asyncio.run(p._process_frame_batch(mixed, [(0, 0.0), (1, 0.1), (2, 0.2)], "/tmp"))
+    assert p.route_counts == {"device": 3, "reference": 0} and [o["frame_number"] for o in out] == [0, 1, 2]
     for o, f in zip(out, mixed):
         e = opipe.process_frame_batch([f], [(0, 0.0)], det_sd, "resnet18", rec_sd, 0.5)[0]
         _same(o["detections"], e["detections"], rec_sd, f)
