@@ -11,8 +11,13 @@ For N>1 every rank runs its own 32 frames (weak scaling, frames shard with no da
 only exchange is the gather of detection records to every rank (RCCL all_gather of a small padded block).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
-implicit-GEMM convolution, timed with HIP events on its launch stream across the timed region) and
-`cpu_baseline` (the CPU oracle timed on this host on a bounded sample of the same workload).
+implicit-GEMM convolution, timed with HIP events on its launch stream across the timed region),
+`cpu_baseline` (the CPU oracle timed on this host on a bounded sample of the same workload, in the two shapes of
+BASELINE.md section 4: reference-shaped N=1 calls from 4 threads, and best-case batched) and `sustained` (the same step
+back to back for >= 5 s after the timed region, with the shader clocks the host reports before and after).
+
+Every leg rotates over ROTATE distinct resident batches (4 x 88 MB at 720p: more than the 256 MB Infinity Cache), so no
+step reads a batch that an earlier step left in cache.
 """
 import argparse
 import json
@@ -26,6 +31,7 @@ for _p in (os.path.join(ROOT, "video-text-detection-system_amd"), ROOT):
         sys.path.insert(0, _p)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+ROTATE = 4                 # distinct resident input batches per rank
 
 
 def parse():
@@ -42,8 +48,11 @@ def parse():
     ap.add_argument("--recognizer", default="crnn", choices=["crnn", "trocr"],
                     help="crnn = BASELINE configs[2]; trocr = the Transformer recogniser of configs[4] (trocr-base-printed architecture, seeded weights)")
     ap.add_argument("--mixed", action="store_true",
-                    help="BASELINE configs[4] batch: half of the frames 720p, half 1080p (two equally sized sub-batches per step)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline sample (0 = skip)")
+                    help="BASELINE configs[4] batch: frames alternate 720p / 1080p; the pipeline groups them by shape (one device pass per "
+                         "size, results back in frame order) exactly as process_video does")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget PER SHAPE for the cpu_baseline samples (0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="length of the sustained leg after the timed region (0 = skip); reported as `sustained`, never as `value`")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
     ap.add_argument("--upload", action="store_true",
                     help="PCIe-inclusive variant (not the headline value): every step uploads its batch from pinned host memory "
@@ -155,18 +164,25 @@ def main():
         dist.init_process_group(os.environ.get("VTD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     B, H, W = args.batch, args.height, args.width
-    if args.mixed:   # configs[4]: alternating 720p / 1080p frames, processed as one 720p and one 1080p sub-batch per step
-        if args.upload or args.workload != "full" or B % 2:
-            raise SystemExit("--mixed needs --workload full, an even --batch and no --upload")
-        sizes = [(720, 1280), (1080, 1920)]
-        sub = [np.stack([synth.text_frame(2000 + rank * B + 2 * i + k, *sizes[k])[0] for i in range(B // 2)]) for k in range(2)]
-        sub_frames = [DeviceFrames(f) for f in sub]
-        frames = sub[0]
+    SIZES = [(720, 1280), (1080, 1920)]
+    if args.mixed and (args.upload or args.workload != "full" or B % 2):
+        raise SystemExit("--mixed needs --workload full, an even --batch and no --upload")
+
+    def host_batch(k):
+        """Batch k of this rank (k = 0..ROTATE-1), every frame with its own seed: list of HxWx3 uint8 arrays."""
+        base = (2000 if args.mixed else 100) + (rank * ROTATE + k) * B
+        return [synth.text_frame(base + i, *(SIZES[i % 2] if args.mixed else (H, W)))[0] for i in range(B)]
+
+    host_batches = [host_batch(k) for k in range(ROTATE)]
+    frames = host_batches[0]                                   # the CPU baseline's sample comes from the same frames
+    if args.mixed:      # resident per-frame tensors of two sizes: the pipeline groups them by shape at every step
+        mixed_batches = [[torch.from_numpy(f).cuda() for f in hb] for hb in host_batches]
+        dev_batches = None
     else:
-        frames = np.stack([synth.text_frame(100 + rank * B + i, H, W)[0] for i in range(B)])
-    dev_frames = DeviceFrames(frames)
+        dev_batches = [DeviceFrames(np.stack(hb)) for hb in host_batches]
+    resident_mb = sum(f.nbytes for hb in host_batches for f in hb) / 1e6
     if args.upload:
-        host_frames = torch.from_numpy(frames).pin_memory()
+        pinned_batches = [torch.from_numpy(np.stack(hb)).pin_memory() for hb in host_batches]
         upload_stream = torch.cuda.Stream()
     sd = weights.margin_detector_state_dict(args.backbone, 0)
     from vtd_amd import nets as mynets
@@ -187,16 +203,20 @@ def main():
     eng = pipe.detector.model.engine()
     lib = eng.lib
     last = {}
+    crops_seen = {"n": 0, "batches": 0}
 
     inflight = {"det": None, "rec": None}
 
     turn = {"k": 0}
 
     def next_batch():
-        if args.mixed:
-            turn["k"] ^= 1
-            return sub_frames[turn["k"] ^ 1]
-        return DeviceFrames(host_frames, stream=upload_stream) if args.upload else dev_frames
+        k = turn["k"] = (turn["k"] + 1) % ROTATE
+        return DeviceFrames(pinned_batches[k], stream=upload_stream) if args.upload else dev_batches[k]
+
+    def note(results):
+        last["results"] = results
+        crops_seen["n"] += sum(len(r["detections"]) for r in results)
+        crops_seen["batches"] += 1
 
     def step_detector():
         # the product's detector half, two batches in flight: enqueue batch i (preprocess -> DBNet on the caller's stream,
@@ -205,7 +225,7 @@ def main():
         if inflight["det"] is not None:
             last["detections"] = pipe.detector.finish_batch(inflight["det"])
         inflight["det"] = t
-        return t["keep"][1][:B], t["keep"][2][:B]
+        return [(t["keep"][1][:B], t["keep"][2][:B])]
 
     def drain_detector():
         if inflight["det"] is not None:
@@ -219,44 +239,63 @@ def main():
         job = pipe.submit_detection(next_batch())
         keep = job["det"]["keep"]
         if inflight["rec"] is not None:
-            last["results"] = pipe.collect(inflight["rec"])
+            note(pipe.collect(inflight["rec"]))
             inflight["rec"] = None
         if inflight["det"] is not None:
             inflight["rec"] = pipe.submit_recognition(inflight["det"])
         inflight["det"] = job
-        return keep[1][:B], keep[2][:B]
+        return [(keep[1][:B], keep[2][:B])]
 
     def drain_full():
         while inflight["det"] is not None or inflight["rec"] is not None:
             if inflight["rec"] is not None:
-                last["results"] = pipe.collect(inflight["rec"])
+                note(pipe.collect(inflight["rec"]))
                 inflight["rec"] = None
             if inflight["det"] is not None:
                 inflight["rec"] = pipe.submit_recognition(inflight["det"])
                 inflight["det"] = None
 
+    # configs[4]: the batch alternates 720p / 1080p.  It goes through the very entry process_video uses (_pipeline_push): frames are
+    # grouped by shape, each group is one device pass, the groups ride the three-deep pipeline and come back in frame order.
+    mixed_info = [(i, i / 30.0) for i in range(B)]
+
+    def step_mixed():
+        k = turn["k"] = (turn["k"] + 1) % ROTATE
+        done = pipe._pipeline_push(mixed_batches[k], mixed_info)
+        if done:
+            note(done)
+        jobs = [j for j in pipe._inflight if not j.get("failed")][-len(SIZES):]   # this push's two shape groups
+        return [(j["det"]["keep"][1], j["det"]["keep"][2]) for j in jobs if "det" in j]
+
+    def drain_mixed():
+        done = pipe._pipeline_drain()
+        if done:
+            note(done[-B:])
+
+    step_once = step_mixed if args.mixed else step_full if args.workload == "full" else step_detector
+    drain = drain_mixed if args.mixed else drain_full if args.workload == "full" else drain_detector
+
     def step():
-        if args.mixed:
-            step_full()
-        rec, cnt = step_full() if args.workload == "full" else step_detector()
+        blocks = step_once()
         if world > 1:
             # the one exchange step of the path: detection records of every rank to every rank.  Enqueued on the stream
             # that produced them (the detector's post-process side stream), so it is ordered behind the records without
             # stalling the caller's stream, where the next batch's DBNet is already queued.
             side = pipe.detector._post_stream()
             with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
-                last["gathered"] = shard.gather_detections(rec, cnt)
-        return rec, cnt
+                for rec, cnt in blocks:
+                    last["gathered"] = shard.gather_detections(rec, cnt)
+        return blocks
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    drain = drain_full if args.workload == "full" else drain_detector
-    # one priming step whatever --warmup says: the first call at a batch size runs the per-layer autotune and the workspace
-    # allocations (hundreds of ms), which are set-up cost, not a step of the path
-    step()
+    # one priming pass over every resident batch whatever --warmup says: the first call at a batch size runs the per-layer
+    # autotune and the workspace allocations (hundreds of ms), which are set-up cost, not a step of the path
+    for _ in range(ROTATE if args.mixed else 1):
+        step()
     drain()
     for _ in range(args.warmup):
         step()
@@ -275,9 +314,10 @@ def main():
         survey = detector_profile(eng)
         dom = max(range(len(survey)), key=lambda i: survey[i][1] if survey[i][3] > 0 else -1.0)
         lib.vtd_detector_set_profiling(eng.handle, 2 + dom)
+    crops_seen["n"] = crops_seen["batches"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rec, cnt = step()
+        blocks = step()
     drain()  # K batches submitted -> K batches retired (result dicts built) inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
@@ -285,10 +325,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    crops_per_step = crops_seen["n"] / max(crops_seen["batches"], 1)
 
     # ---- sanity: the timed path produced detections (not part of the timed region)
-    counts = cnt.cpu().numpy()
-    n_det = int(counts.sum())
+    n_det = int(sum(int(cnt.sum().item()) for _, cnt in blocks))
 
     roofline = None
     layer_rows = []
@@ -307,32 +347,7 @@ def main():
         conv_us = sum(r[1] for r in convs) * 1e3  # per step, survey pass
         # algorithmic (reference-graph) FLOPs of the whole detector per step, SURVEY 8d: 69.8 GFLOP / frame for R18
         algo_flops_step = 2.0 * eng.macs_per_frame * B
-        traffic = traffic_detail = None
-        try:  # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/, FETCH_SIZE x2 corrected)
-            import glob
-            pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_per_launch.json")))[-1]
-            pmc = json.load(open(pmc_path))
-
-            def pick(substr):
-                hits = [v for k, v in pmc.items() if substr in k and v["launches"] >= 3]
-                return max(hits, key=lambda h: h["launches"]) if hits else None
-
-            # launch-slot description (vtd_api.cpp) -> device kernel symbol of exactly that variant
-            symbol = next((sym for key, sym in (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
-                                                ("head_entry_halo256", "head_entry_halo256_kernel<false>("),
-                                                ("head_entry_halo ", "head_entry_halo_kernel<"),
-                                                ("classed", "true>(")) if key in name), None)
-            parts = [v for v in [pick(symbol) if symbol else None] if v]
-            if parts:
-                rd = sum(v["hbm_read_MB_corrected_x2"] for v in parts)
-                wr = sum(v["hbm_write_MB"] for v in parts)
-                traffic = int((rd + wr) * 1e6)
-                traffic_detail = {"hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2),
-                                  "kernel_symbol": symbol,
-                                  "source": "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                            "median over launches, FETCH_SIZE x2 per the gfx950 note)"}
-        except Exception:
-            traffic = traffic_detail = None
+        traffic, traffic_detail, traffic_error = lookup_traffic(name)
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
@@ -350,30 +365,40 @@ def main():
                     "all_mfma_launches_tflops_executed": round(sum(2 * r[2] for r in convs) / (conv_us * 1e-6) / 1e12, 2),
                     "net_algorithmic_tflops": round(algo_flops_step / (conv_us * 1e-6) / 1e12, 2),
                     "detector_mfma_launches_us_per_step": round(conv_us, 1)}
+        if traffic_error:
+            roofline["traffic_error"] = traffic_error
+            print("bench.py: " + traffic_error, file=sys.stderr)
+            if os.environ.get("VTD_BENCH_STRICT") == "1":
+                raise SystemExit(2)
         if args.layers_out and rank == 0:
             with open(args.layers_out, "w") as f:
                 json.dump(layer_rows, f, indent=1)
 
+    # ---- sustained leg (not `value`): the same step back to back for >= --sustain-seconds, clocks before and after
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)) + 1)   # same count on every rank (elapsed is the MAX)
+        clk0 = read_sclk_mhz()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        drain()
+        barrier()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sustained = {"seconds": round(dt, 3), "steps": n_sus, "value": round(world * B * n_sus / dt, 2), "unit": "frames/s",
+                     "ms_per_step": round(dt / n_sus * 1e3, 3), "vs_timed_region": round((world * B * n_sus / dt) / (world * B * args.steps / elapsed), 4),
+                     "sclk_mhz_before": clk0, "sclk_mhz_after": read_sclk_mhz(),
+                     "what": "same steps back to back, started right after the timed region; sclk = current level of every card the host "
+                             "exposes under /sys/class/drm (ours is among them), read just before and just after the leg"}
+
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
-        from oracle import pipeline as opipe
-        # the 1-GPU box grants a 16-CPU share of a much larger host: more threads than that only thrash
-        ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VTD_CPU_CORES", "16")))
-        torch.set_num_threads(ncores)
-        def cpu_frame(fr):
-            if args.workload == "full":  # reference-shaped: one detect per frame, one recognize per crop (pipeliine.py:96-133)
-                return opipe.process_frame_batch([fr], [(0, 0.0)], sd, args.backbone, rec_sd, 0.5)
-            return opipe.detect(fr, sd, args.backbone, 0.5)
-        cpu_frame(frames[0])  # warm-up (oneDNN primitive creation)
-        done, t_cpu = 0, time.perf_counter()
-        while done < B and time.perf_counter() - t_cpu < args.cpu_seconds:
-            cpu_frame(frames[done])
-            done += 1
-        dt = time.perf_counter() - t_cpu
-        what = ("preprocess + DBNet-%s fp32 torch CPU + C post-process%s" %
-                (args.backbone, " + per-crop cv-resize + CRNN fp32 + CTC decode" if args.workload == "full" else ""))
-        cpu_baseline = {"value": round(done / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                        "sample": f"{done} of the {B} {H}p frames, one at a time ({what})"}
+        cpu_baseline = cpu_baselines(args, frames, sd, rec_sd)
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -392,19 +417,143 @@ def main():
             "data": "synthetic" + (" (uploaded from pinned host memory every step: PCIe-inclusive variant)" if args.upload else ""),
             "config": {"workload": (f"B={B} {H}p frames, DBNet-{args.backbone} detector only (preprocess+net+post-process), fp16"
                                     if args.workload == "detector" else
-                                    f"B={B} {'mixed 720p/1080p' if args.mixed else str(H) + 'p'} frames, full pipeline: DBNet-{args.backbone} + crop + "
+                                    f"B={B} {'mixed 720p/1080p (alternating, grouped by shape on the device path)' if args.mixed else str(H) + 'p'} frames, full pipeline: DBNet-{args.backbone} + crop + "
                                     + ("TrOCR (ViT-base-384 encoder + 12-layer decoder, greedy max_length=50)" if args.recognizer == "trocr"
                                        else "CRNN + CTC decode") + " -> result dicts, fp16"),
-                       "global_batch": world * B, "frame": [H, W], "backbone": args.backbone,
+                       "global_batch": world * B, "frame": "alternating 720x1280 / 1080x1920" if args.mixed else [H, W], "backbone": args.backbone,
                        "parallelism": f"frames sharded over {world} rank(s), detections all-gathered",
+                       "resident_input": f"{ROTATE} distinct batches per rank, {resident_mb:.0f} MB, visited round-robin",
                        "detections_last_step_rank0": n_det,
+                       "crops_recognized_per_step_rank0": round(crops_per_step, 1),
                        "crops_recognized_last_step_rank0": (sum(len(r["detections"]) for r in last["results"]) if "results" in last else 0)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "sustained": sustained,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def read_sclk_mhz():
+    """Current shader-clock level of every card under /sys/class/drm (the line pp_dpm_sclk marks with '*'), in MHz."""
+    import glob
+    import re
+    out = []
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            cur = [ln for ln in open(path).read().splitlines() if ln.rstrip().endswith("*")]
+            m = re.search(r"(\d+)\s*Mhz", cur[0], re.I) if cur else None
+            out.append(int(m.group(1)) if m else None)
+        except OSError:
+            out.append(None)
+    return out
+
+
+# launch-slot description (vtd_api.cpp: vtd_detector_get_profile) -> device kernel symbol of exactly that variant
+KERNEL_SYMBOLS = (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
+                  ("head_entry_halo256", "head_entry_halo256_kernel<false>("), ("head_entry_halo ", "head_entry_halo_kernel<"),
+                  ("classed", "true>("))
+
+
+def lookup_traffic(launch_name, profiles_dir=None):
+    """HBM bytes per launch of the dominant kernel, from the newest committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic_per_launch.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 per the gfx950 note; PMC counters cannot be collected inside this process).
+    Returns (bytes, detail, error): a dominant kernel the file does not cover is an ERROR the JSON line carries (`traffic_error`) and
+    tests/test_bench_launcher.py turns into a failing CPU test for the shipped selection -- never a silent null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_traffic_per_launch.json")))
+    if not files:
+        return None, None, "roofline.traffic: no profiles/r*_pmc_traffic_per_launch.json in the tree"
+    pmc_path = files[-1]
+    symbol = next((sym for key, sym in KERNEL_SYMBOLS if key in launch_name), None)
+    if symbol is None:
+        return None, None, f"roofline.traffic: no kernel symbol known for the dominant launch {launch_name!r} (bench.py KERNEL_SYMBOLS)"
+    try:
+        pmc = json.load(open(pmc_path))
+    except (OSError, ValueError) as e:
+        return None, None, f"roofline.traffic: cannot read {pmc_path}: {e}"
+    hits = [v for k, v in pmc.items() if symbol in k and v.get("launches", 0) >= 3]
+    if not hits:
+        return None, None, (f"roofline.traffic: {os.path.basename(pmc_path)} has no entry for kernel symbol {symbol!r}: the PMC passes are "
+                            "stale for the kernel that now dominates -- re-run tools/gpu_evidence.sh and commit the summary")
+    v = max(hits, key=lambda h: h["launches"])
+    rd, wr = v["hbm_read_MB_corrected_x2"], v["hbm_write_MB"]
+    detail = {"hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2), "kernel_symbol": symbol,
+              "source": "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median over launches, "
+                        "FETCH_SIZE x2 per the gfx950 note)"}
+    return int((rd + wr) * 1e6), detail, None
+
+
+def cpu_baselines(args, frames, sd, rec_sd):
+    """The oracle (CPU restatement, fp32 torch + C stages) timed on this host in the two shapes of BASELINE.md section 4, each on a bounded
+    sample of the bench's own frames: (i) reference-shaped -- one N=1 detect per frame from 4 threads, then one recognise call per
+    crop, as pipeliine.py:32,96-133 does; (ii) best-case batched -- all sampled frames in one forward, all crops in one batch."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cstages, nets as onets, pipeline as opipe
+    B = len(frames)
+    # the 1-GPU box grants a 16-CPU share of a much larger host: more threads than that only thrash
+    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("VTD_CPU_CORES", "16")))
+    torch.set_num_threads(ncores)
+    full, trocr = args.workload == "full", args.recognizer == "trocr"
+    if trocr:
+        from oracle import trocr as otrocr
+        from vtd_amd._fixtures import weights
+        from vtd_amd.trocr_spec import BASE_PRINTED
+        tsd = weights.trocr_state_dict(BASE_PRINTED, seed=int(os.environ.get("VTD_TROCR_SEEDED", "0") or 0))
+
+    def crops_of(fr, dets):
+        return [fr[d["bbox"][1]:d["bbox"][3], d["bbox"][0]:d["bbox"][2]] for d in dets
+                if d["bbox"][2] > d["bbox"][0] and d["bbox"][3] > d["bbox"][1]]
+
+    def recognise_one(crop):
+        if trocr:
+            return otrocr.recognize_ids([crop], tsd, BASE_PRINTED)
+        return opipe.recognize_batch([crop], rec_sd)
+
+    def recognise_all(crops):
+        if not crops:
+            return []
+        if trocr:
+            x = torch.stack([otrocr.preprocess(c, BASE_PRINTED) for c in crops])
+            return otrocr.generate(otrocr.encode(x, tsd, BASE_PRINTED), tsd, BASE_PRINTED)[0]
+        return opipe.recognize_batch(crops, rec_sd)
+
+    opipe.detect(frames[0], sd, args.backbone, 0.5)  # warm-up (oneDNN primitive creation)
+    # (i) reference-shaped: rounds of 4 frames, detect on a 4-thread pool, crops one by one (pipeliine.py:96-133)
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        while done < B and time.perf_counter() - t0 < args.cpu_seconds:
+            chunk = frames[done:done + 4]
+            dets = list(pool.map(lambda f: opipe.detect(f, sd, args.backbone, 0.5), chunk))
+            if full:
+                for fr, ds in zip(chunk, dets):
+                    for crop in crops_of(fr, ds):
+                        recognise_one(crop)
+            done += len(chunk)
+    dt_ref = time.perf_counter() - t0
+    shaped = {"value": round(done / dt_ref, 3), "unit": "frames/s", "cores": ncores, "threads": "4 Python threads x torch intra-op pool",
+              "sample": f"{done} of the step's {B} frames"}
+    # (ii) best-case batched: one forward over the sample, every crop in one recogniser batch
+    nb = B if args.cpu_seconds >= 10 and not trocr else max(1, min(B, 4 if trocr else 8))
+    sample = frames[:nb]
+    t0 = time.perf_counter()
+    x = torch.cat([opipe.preprocess(f) for f in sample])
+    prob = onets.dbnet_forward(x, sd, args.backbone)["probability"][:, 0].numpy()
+    dets = [cstages.postprocess(prob[i], sample[i].shape[1], sample[i].shape[0], 0.5) for i in range(nb)]
+    if full:
+        recognise_all([c for fr, ds in zip(sample, dets) for c in crops_of(fr, ds)])
+    dt_b = time.perf_counter() - t0
+    batched = {"value": round(nb / dt_b, 3), "unit": "frames/s", "cores": ncores, "sample": f"one batched pass over {nb} of the step's {B} frames"}
+    what = ("preprocess + DBNet-%s fp32 torch CPU + C post-process%s" %
+            (args.backbone, ((" + TrOCR fp32 (ViT-base encoder, 12-layer decoder, greedy)" if trocr else " + cv-resize + CRNN fp32 + CTC decode")
+                             if full else "")))
+    best = max(shaped, batched, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": ("best of the two shapes below (%s): %s; %s" % ("batched" if best is batched else "reference-shaped", best["sample"], what)),
+            "reference_shaped_4_threads": shaped, "batched_B%d" % nb: batched}
 
 
 if __name__ == "__main__":

@@ -36,3 +36,27 @@ def test_failed_rank_fails_the_bench():
 def test_world_size_mismatch_is_an_error():
     r = _run("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
     assert r.returncode != 0 and "does not match" in r.stderr
+
+
+def test_roofline_traffic_lookup_covers_the_shipped_dominant_kernel_and_fails_loudly_otherwise(tmp_path):
+    """bench.py cites HBM bytes per launch from the committed rocprofv3 --pmc summary.  The summary must hold the kernel the shipped
+    kernel-selection table runs as the dominant launch (the composed head entry on head_entry_halo256 at B = 32), and a dominant
+    kernel it does not hold must surface as an error string in the JSON line, never as a silent null."""
+    import json
+    import bench
+    name = "head_entry_halo256 M/img=25600 N=64 K=3904 (lateral+smooth+head conv composed; border classes in the next slot)"
+    traffic, detail, err = bench.lookup_traffic(name)
+    assert err is None and traffic > 100e6 and detail["kernel_symbol"] == "head_entry_halo256_kernel<false>("
+    # the shipped table really selects that kernel for the composed head entry at the bench's batch
+    table = open(os.path.join(ROOT, "video-text-detection-system_amd", "vtd_amd", "tuning", "gfx950.txt")).read().splitlines()
+    classed = [ln for ln in table if ln.startswith("conv|in160x160x64|") and "|c1|n32 " in ln]
+    assert classed and all(ln.rsplit(" ", 1)[1] == "103" for ln in classed), classed
+    # stale or missing summaries
+    (tmp_path / "r09_pmc_traffic_per_launch.json").write_text(json.dumps({"some_other_kernel(": {"launches": 9, "hbm_read_MB_corrected_x2": 1.0,
+                                                                                                  "hbm_write_MB": 1.0}}))
+    t, d, err = bench.lookup_traffic(name, profiles_dir=str(tmp_path))
+    assert t is None and d is None and "no entry for kernel symbol" in err
+    t, d, err = bench.lookup_traffic("a brand-new kernel", profiles_dir=str(tmp_path))
+    assert t is None and "no kernel symbol known" in err
+    t, d, err = bench.lookup_traffic(name, profiles_dir=str(tmp_path / "empty"))
+    assert t is None and "no profiles/" in err
