@@ -31,6 +31,7 @@ for _p in (os.path.join(ROOT, "video-text-detection-system_amd"), ROOT):
         sys.path.insert(0, _p)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0      # HBM3E, same guide
 ROTATE = 4                 # distinct resident input batches per rank
 
 
@@ -238,11 +239,11 @@ def main():
     def step_full():
         job = pipe.submit_detection(next_batch())
         keep = job["det"]["keep"]
-        if inflight["rec"] is not None:
-            note(pipe.collect(inflight["rec"]))
-            inflight["rec"] = None
-        if inflight["det"] is not None:
+        ready, inflight["rec"] = inflight["rec"], None
+        if inflight["det"] is not None:   # same order as VideoTextPipeline._pipeline_push: recogniser of batch i-1 first ...
             inflight["rec"] = pipe.submit_recognition(inflight["det"])
+        if ready is not None:             # ... then the result dicts of batch i-2 (the Transformer's decode of i-2 overlaps the encoder pass of i-1)
+            note(pipe.collect(ready))
         inflight["det"] = job
         return [(keep[1][:B], keep[2][:B])]
 
@@ -315,6 +316,10 @@ def main():
         dom = max(range(len(survey)), key=lambda i: survey[i][1] if survey[i][3] > 0 else -1.0)
         lib.vtd_detector_set_profiling(eng.handle, 2 + dom)
     crops_seen["n"] = crops_seen["batches"] = 0
+    teng = pipe.recognizer.model.engine() if args.recognizer == "trocr" and args.workload == "full" else None
+    if teng is not None and not args.no_profile:
+        teng.profile()                 # drop what the warm-up left
+        teng.set_profiling(1)          # HIP events around the decoder's cross-attention launch (layer 0 of every step), on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         blocks = step()
@@ -373,6 +378,30 @@ def main():
         if args.layers_out and rank == 0:
             with open(args.layers_out, "w") as f:
                 json.dump(layer_rows, f, indent=1)
+
+    if teng is not None and not args.no_profile:
+        # The Transformer line is bound by its recogniser, and the recogniser's dominant launch is HBM-bound: the decoder's cross-attention
+        # reads the encoder keys / values of every live row (T tokens x D x fp16, K and V) once per layer and step.
+        ms, calls, rows = teng.profile()
+        teng.set_profiling(0)
+        spec = pipe.recognizer.model.spec
+        if calls:
+            bytes_total = rows * spec.enc_tokens * spec.dec_hidden * 2 * 2
+            achieved = bytes_total / (ms * 1e-3) / 1e9
+            traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")
+            detector_roofline = roofline
+            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
+                        "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
+                        "algorithmic_bytes_per_launch": int(bytes_total / calls),
+                        "note": "algorithmic bytes = live rows x encoder tokens (577) x d_model (1024) x 2 B x (K + V): every byte is read once per "
+                                "launch; rows that have emitted </s> are not read (the live list shrinks from ~272 to a handful over a batch), so "
+                                "late launches are latency-bound, not bandwidth-bound; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)",
+                        "detector_dominant_kernel": detector_roofline}
+            if traffic_error:
+                roofline["traffic_error"] = traffic_error
+                print("bench.py: " + traffic_error, file=sys.stderr)
 
     # ---- sustained leg (not `value`): the same step back to back for >= --sustain-seconds, clocks before and after
     sustained = None
@@ -453,7 +482,7 @@ def read_sclk_mhz():
 # launch-slot description (vtd_api.cpp: vtd_detector_get_profile) -> device kernel symbol of exactly that variant
 KERNEL_SYMBOLS = (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
                   ("head_entry_halo256", "head_entry_halo256_kernel<false>("), ("head_entry_halo ", "head_entry_halo_kernel<"),
-                  ("classed", "true>("))
+                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false>("))
 
 
 def lookup_traffic(launch_name, profiles_dir=None):

@@ -180,6 +180,25 @@ int vtd_trocr_encode_pixels(vtd_trocr* t, const float* pixel_values_dev, int ncr
 int vtd_trocr_generate(vtd_trocr* t, int ncrops, int max_length, const int32_t* forced_ids_dev, int forced_len, int32_t* ids_dev, float* logits_dev,
                        vtd_stream stream);
 /* Test taps as float32 on the host: "pixel_values" [n,3,S,S], "encoder" (last_hidden_state) [n,tokens,enc_hidden]. */
+/* Two encoder-output slots per handle (vtd_trocr_num_slots): the encoder pass of the next crop batch (ViT + the cross-attention keys /
+ * values of all decoder layers, MFMA-bound) can run on one stream into slot 1 while the previous batch is decoded out of slot 0 on
+ * another (latency- / HBM-bound): `*_slot` variants of the three calls above; the plain ones are slot 0.  The handle orders the passes
+ * itself with events (an encoder pass waits for the decode that last read its slot and for the previous encoder pass; a decode waits for
+ * its slot's encoder pass and for the previous decode), so callers only choose streams.  generate() stops computing a row once it has
+ * emitted </s> (rows leave a compact live list; the ids equal those of generate(), which pads such rows) and returns when all but the
+ * last two steps have run; vtd_trocr_last_steps = decoder steps the last call enqueued. */
+int vtd_trocr_num_slots(const vtd_trocr* t);
+int vtd_trocr_encode_crops_slot(vtd_trocr* t, int slot, const uint8_t* frames_dev, int n_frames, int height, int width, const int32_t* boxes_host,
+                                int ncrops, vtd_stream stream);
+int vtd_trocr_encode_pixels_slot(vtd_trocr* t, int slot, const float* pixel_values_dev, int ncrops, vtd_stream stream);
+int vtd_trocr_generate_slot(vtd_trocr* t, int slot, int ncrops, int max_length, const int32_t* forced_ids_dev, int forced_len, int32_t* ids_dev,
+                            float* logits_dev, vtd_stream stream);
+int vtd_trocr_last_steps(const vtd_trocr* t);
+/* Measurement hook (bench.py roofline of the Transformer line): mode 1 brackets the cross-attention launch of decoder layer 0 of every
+ * step with HIP events on the decode stream; get_profile returns their summed time, the number of launches and the summed row counts the
+ * launches read (exact live-row counts), then resets.  While profiling is on, generate() waits for its own completion. */
+int vtd_trocr_set_profiling(vtd_trocr* t, int mode);
+int vtd_trocr_get_profile(vtd_trocr* t, double* total_ms, int64_t* launches, int64_t* row_launches, vtd_stream stream);
 int vtd_trocr_read_tap(vtd_trocr* t, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream);
 int vtd_trocr_encoder_tokens(const vtd_trocr* t);
 int vtd_trocr_logits_stride(const vtd_trocr* t);

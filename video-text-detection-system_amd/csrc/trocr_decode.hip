@@ -1,0 +1,456 @@
+// Autoregressive decoder of the Transformer recogniser (TrOCR; text_recognizer.py:55-60 -> transformers TrOCRForCausalLM + greedy
+// generate) as a chain of small gfx950 kernels over a COMPACT list of live rows.
+//
+// Shape of the problem: one query row per crop and step (M = a few hundred rows at most, shrinking as rows emit </s>), 12 layers,
+// ~11 dependent launches per layer.  Nothing here is MFMA- or HBM-bound except the cross-attention read of the encoder keys / values;
+// what decides the step time is the fixed cost of every launch in the chain, so the kernels are built for latency:
+//
+//  * dec_gemm: out[M, N] = A[M, K] * W[N, K]^T for M <= a few hundred.  A workgroup owns a (16 MF) x (16 NF) output tile; its four
+//    waves split the K range four ways (no barrier, no LDS in the K loop: every wave streams its own fragments straight into
+//    registers, four 32-deep sub-steps per batch of loads) and meet once, through LDS, for the final sum.  Optional split-K over
+//    workgroups writes fp32 partial slabs that the NEXT kernel of the chain (the LayerNorm) sums -- the launch-boundary combine of
+//    cdna_hip_programming.md section 5 ("Projection GEMM at M = 256", item 2): no atomics, fixed summation order, bitwise repeatable.
+//  * dec_ln: residual + bias + split-K slabs -> LayerNorm -> fp32 stream + fp16 GEMM input, one wave per row.
+//  * dec_self_attn / dec_cross_attn: one wave per (row, head), eight lanes per 128-byte key / value row; the self-attention wave also
+//    files the step's new key / value into the crop's cache rows.
+//  * dec_argmax + dec_advance: greedy token, GenerationMixin's </s> / <pad> bookkeeping, and the COMPACTION of the row list: rows that
+//    emitted </s> leave `active[]`, so every later kernel runs on the live rows only (per-row buffers are indexed by list position j,
+//    caches / ids / encoder keys by crop = active[j]).  The live count goes to device memory (exact, read by every kernel) and to
+//    pinned host memory (read by the host two steps late as an upper bound for the launch geometry and as the stop test).
+#include <cmath>
+#include "vtd_common.h"
+
+namespace {
+
+constexpr int DG_OUT_F16 = 1, DG_GELU = 2, DG_PARTIAL = 4;
+
+struct DecGemmParams {
+    const half_t* A;      // [rows][lda] fp16
+    const half_t* W;      // [N rounded up to the tile][K] fp16 (build_linear's layout)
+    const float* bias;    // [N rounded up to the tile] (ignored for DG_PARTIAL)
+    void* out;            // fp16 / fp32 [rows][ldc]; DG_PARTIAL: fp32 slabs, slab z at out + z * slab_stride
+    int64_t slab_stride;
+    const int* n_rows;    // device: exact live row count (<= M)
+    int lda, ldc, M, N, K, ksplit, flags;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int MF, int NF, int RF>
+__device__ __forceinline__ void finish_fragment(const DecGemmParams& p, const float* red, int f, int pass, int lane, int fr, int fq, int m0, int n0,
+                                                int rows) {
+        floatx4 v = *(const floatx4*)(red + ((0 * RF + f - pass) * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v += *(const floatx4*)(red + ((q * RF + f - pass) * 64 + lane) * 4);   // fixed order: wave 0 + 1 + 2 + 3
+        const int i = f / NF, j = f - i * NF;
+        const int m = m0 + i * 16 + fr, n = n0 + j * 16 + fq * 4;   // lane: row fr, four consecutive columns
+        if (m >= rows || n >= p.N) return;
+        if (p.flags & DG_PARTIAL) {
+            float* o = (float*)p.out + (int64_t)blockIdx.z * p.slab_stride + (int64_t)m * p.ldc + n;
+            if (n + 3 < p.N) *(floatx4*)o = v;
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = v[e];
+            return;
+        }
+        v += *(const floatx4*)(p.bias + n);   // the bias vector is padded with zeros to the tile width (build_linear)
+        if (p.flags & DG_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.flags & DG_OUT_F16) {
+            half_t* o = (half_t*)p.out + (int64_t)m * p.ldc + n;
+            if (n + 3 < p.N) *(half4*)o = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = (half_t)v[e];
+        } else {
+            float* o = (float*)p.out + (int64_t)m * p.ldc + n;
+            if (n + 3 < p.N && !(((uintptr_t)o) & 15)) *(floatx4*)o = v;
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = v[e];
+        }
+}
+
+template <int MF, int NF>
+__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * (MF * NF < 8 ? MF * NF : 8) * 256];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int rows = min(*p.n_rows, p.M);
+    const int m0 = blockIdx.y * (16 * MF), n0 = blockIdx.x * (16 * NF);
+    if (m0 >= rows) return;   // uniform over the workgroup, before any barrier
+    // the workgroup's K range in 32-deep sub-steps, dealt to the four waves as evenly as they divide (K = 192: 1 + 2 + 1 + 2)
+    const int kper = p.K / p.ksplit, nsub = kper >> 5;     // host guarantees kper % 32 == 0
+    const int sub0 = (nsub * w) >> 2, klen = (((nsub * (w + 1)) >> 2) - sub0) << 5;
+    const int kbeg = blockIdx.z * kper + (sub0 << 5);
+    // rows past the live count are read (the buffers hold max_crops rows, rounded up to the tile) and never written
+    const half_t* ap = p.A + (int64_t)(m0 + fr) * p.lda + kbeg + fq * 8;
+    const half_t* wp = p.W + (int64_t)(n0 + fr) * p.K + kbeg + fq * 8;
+    floatx4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = (MF + NF) <= 6 ? 4 : 2;   // 32-deep sub-steps whose loads are issued together (<= 24 x 16 bytes per lane in flight)
+    for (int k = 0; k < klen; k += 32 * U) {
+        half8 a[U][MF], b[U][NF];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = (k + 32 * u < klen) ? k + 32 * u : k;   // a short tail re-reads its first sub-step (result unused)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) b[u][j] = *(const half8*)(wp + (int64_t)j * 16 * p.K + kk);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) a[u][i] = *(const half8*)(ap + (int64_t)i * 16 * p.lda + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + 32 * u < klen) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][j], a[u][i], acc[i][j], 0, 0, 0);
+            }
+    }
+    // four K quarters -> one tile: the waves park their accumulators (eight fragments per pass: 32 KB of LDS), then wave w finishes
+    // fragments w, w + 4, ... of the pass
+    constexpr int RF = MF * NF < 8 ? MF * NF : 8;
+#pragma unroll
+    for (int pass = 0; pass < MF * NF; pass += RF) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int f = i * NF + j;
+                if (f >= pass && f < pass + RF) *(floatx4*)(red + ((w * RF + f - pass) * 64 + lane) * 4) = acc[i][j];
+            }
+        __syncthreads();
+        for (int f = pass + w; f < pass + RF; f += 4) finish_fragment<MF, NF, RF>(p, red, f, pass, lane, fr, fq, m0, n0, rows);
+    }
+}
+
+// ---- LayerNorm of the decoder (post-LN): t = x + bias + sum of split-K slabs (residual mode) or embed[token] + position (embedding
+// mode); x <- LN(t), x16 <- fp16(LN(t)).  One wave per row, float4 accesses (D % 64 == 0, D <= 2048).
+struct DecLnParams {
+    float* x;              // [rows][D] residual stream (in / out)
+    half_t* x16;           // [rows][D]
+    const float* slabs;    // residual mode: [nsplit][slab_stride] fp32 partial sums, row stride D
+    int64_t slab_stride;
+    int nsplit;
+    const float* bias;     // [D]
+    const float *gamma, *beta;
+    const int* n_rows;
+    int M, D;
+    float eps;
+    // embedding mode (embed != null)
+    const float *embed, *pos;     // [vocab][D], [positions + 2][D]
+    const int32_t* ids;           // [crops][ld_ids]
+    const int32_t* active;        // [rows] -> crop
+    int ld_ids, col, position, vocab;
+};
+
+template <int MAXV4>
+__global__ __launch_bounds__(256) void dec_ln_kernel(DecLnParams p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= min(*p.n_rows, p.M)) return;
+    floatx4 v[MAXV4];
+    float sum = 0.f;
+    const float* erow = nullptr;
+    if (p.embed) {
+        int tok = p.ids[(int64_t)p.active[row] * p.ld_ids + p.col];
+        tok = tok < 0 ? 0 : tok >= p.vocab ? p.vocab - 1 : tok;
+        erow = p.embed + (int64_t)tok * p.D;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        floatx4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c < p.D) {   // D % 4 == 0: a lane's four columns are in or out together
+            if (p.embed) {
+                t = *(const floatx4*)(erow + c) + *(const floatx4*)(p.pos + (int64_t)(p.position + 2) * p.D + c);
+            } else {
+                t = *(const floatx4*)(p.x + (int64_t)row * p.D + c) + *(const floatx4*)(p.bias + c);
+                for (int s = 0; s < p.nsplit; ++s) t += *(const floatx4*)(p.slabs + (int64_t)s * p.slab_stride + (int64_t)row * p.D + c);
+            }
+        }
+        v[i] = t;
+        sum += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i)
+        if ((i * 64 + lane) * 4 < p.D) {
+            const floatx4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)p.D + p.eps);
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.D) {
+            const floatx4 n = (v[i] - mean) * rstd * *(const floatx4*)(p.gamma + c) + *(const floatx4*)(p.beta + c);
+            *(floatx4*)(p.x + (int64_t)row * p.D + c) = n;
+            *(half4*)(p.x16 + (int64_t)row * p.D + c) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
+        }
+    }
+}
+
+// ---- attention of one query row per (list row j, head) against L keys.  K / V rows of a head are one 128-byte line: eight lanes
+// read it (16 bytes each), a wave-instruction covers eight keys in full lines.  SELF: q | k | v of the step come from the fused
+// projection's [rows][3D] buffer; the wave files k / v into the crop's cache row `step` and attends to cache rows 0..step-1 plus the
+// new one.  CROSS: keys / values of the crop's encoder tokens ([crops][T][D], written once per crop by the encoder pass).
+struct DecAttnParams {
+    const half_t* q;       // SELF: [rows][3D] (q at col 0, k at D, v at 2D), pre-scaled q; CROSS: [rows][D]
+    int ldq;
+    half_t *kc, *vc;       // SELF: caches [crops][Lmax][D]; CROSS: encoder keys / values [crops][T][D]
+    int64_t crop_stride;   // elements between crops
+    int L;                 // SELF: step + 1 keys (the last one is the new one); CROSS: T
+    int D;
+    half_t* out;           // [rows][D]
+    const int32_t* active;
+    const int* n_rows;
+    int M;
+};
+
+template <bool SELF>
+__global__ __launch_bounds__(64) void dec_attn_kernel(DecAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* pr = (float*)smem;  // [L rounded up to 8]
+    const int j = blockIdx.y, head = blockIdx.x, lane = threadIdx.x;
+    if (j >= min(*p.n_rows, p.M)) return;
+    const int crop = p.active[j];
+    const int sub = lane >> 3, seg = lane & 7;   // key within a group of eight, 16-byte segment of the row
+    const half_t* qrow = p.q + (int64_t)j * p.ldq + head * 64 + seg * 8;
+    const half8 qv = *(const half8*)qrow;
+    float qf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e];
+    half_t* kb = p.kc + (int64_t)crop * p.crop_stride + head * 64 + seg * 8;
+    half_t* vb = p.vc + (int64_t)crop * p.crop_stride + head * 64 + seg * 8;
+    const int L = p.L, D = p.D;
+    half8 knew = {0, 0, 0, 0, 0, 0, 0, 0}, vnew = knew;
+    if (SELF) {   // this step's key / value: into the cache for the later steps, from registers for this one
+        knew = *(const half8*)(qrow + D);
+        vnew = *(const half8*)(qrow + 2 * D);
+        if (sub == 0) {
+            *(half8*)(kb + (int64_t)(L - 1) * D) = knew;
+            *(half8*)(vb + (int64_t)(L - 1) * D) = vnew;
+        }
+    }
+    float mx = -INFINITY;
+    for (int k0 = 0; k0 < L; k0 += 8) {
+        const int key = k0 + sub;
+        float s = 0.f;
+        if (key < L) {
+            const half8 kv = (SELF && key == L - 1) ? knew : *(const half8*)(kb + (int64_t)key * D);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[e];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s = key < L ? s : -INFINITY;
+        if (seg == 0) pr[key] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __syncthreads();
+    const int lpad = (L + 7) & ~7;
+    float sum = 0.f;
+    for (int key = lane; key < lpad; key += 64) {
+        const float e = key < L ? expf(pr[key] - mx) : 0.f;
+        pr[key] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < L; k0 += 8) {
+        const int key = k0 + sub;
+        if (key < L) {
+            const float pk = pr[key];
+            const half8 vv = (SELF && key == L - 1) ? vnew : *(const half8*)(vb + (int64_t)key * D);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pk * (float)vv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (sub == 0) {
+        half8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (half_t)(acc[e] / sum);
+        *(half8*)(p.out + (int64_t)j * D + head * 64 + seg * 8) = hv;
+    }
+}
+
+// ---- greedy step: arg-max over V logits per live row (lowest index wins ties, as torch.argmax), 16-byte loads.
+__global__ __launch_bounds__(256) void dec_argmax_kernel(const float* __restrict__ logits, int64_t ld, int V, int32_t* __restrict__ best_tok,
+                                                         const int* __restrict__ n_rows, int M) {
+    __shared__ float sm[4];
+    __shared__ int si[4];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= min(*n_rows, M)) return;
+    const float* row = logits + (int64_t)j * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    const int v4 = (!(((uintptr_t)row) & 15)) ? (V >> 2) : 0;
+    for (int i = tid; i < v4; i += 256) {
+        const floatx4 t = *(const floatx4*)(row + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t[e] > best) { best = t[e]; bi = 4 * i + e; }   // a thread walks its indices in increasing order: strict > keeps the lowest
+    }
+    for (int i = 4 * v4 + tid; i < V; i += 256) {
+        const float t = row[i];
+        if (t > best) { best = t; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sm[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sm[w] > best || (sm[w] == best && si[w] < bi)) { best = sm[w]; bi = si[w]; }
+        best_tok[j] = bi;
+    }
+}
+
+// ---- GenerationMixin's bookkeeping for the step and the compaction of the row list (one workgroup).
+// For list row j (crop c = active[j]): token = forced token | <pad> if the row is finished | the arg-max; ids[c][col] = token;
+// </s> finishes the row.  compact != 0: finished rows leave the list (order kept); the new count goes to *n_rows and to the pinned
+// host word host_rows[slot] (the host reads it two steps late: an upper bound for its launch geometry, and zero = stop).
+struct DecAdvanceParams {
+    const int32_t* best_tok;   // [rows]
+    int32_t* ids;              // [crops][ld_ids]
+    int32_t* done;             // [crops]
+    int32_t* active;           // [rows]
+    int* n_rows;
+    volatile int* host_rows;
+    const int32_t* forced;     // [crops][ld_forced] or null
+    int ld_ids, col, ld_forced, forced_len, eos, pad, compact;
+};
+
+__global__ __launch_bounds__(512) void dec_advance_kernel(DecAdvanceParams p) {
+    __shared__ int wsum[8];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rows = *p.n_rows;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    int live_total = 0;
+    for (int j0 = 0; j0 < rows; j0 += 512) {   // rows <= 512 is one pass; larger lists walk in chunks (in-place writes never overtake reads)
+        const int j = j0 + tid;
+        int crop = -1, keep = 0;
+        if (j < rows) {
+            crop = p.active[j];
+            int tok = p.best_tok[j];
+            const int was_done = p.done[crop];
+            if (p.forced) tok = p.col < p.forced_len ? p.forced[(int64_t)crop * p.ld_forced + p.col] : p.pad;
+            else if (was_done) tok = p.pad;
+            p.ids[(int64_t)crop * p.ld_ids + p.col] = tok;
+            int now_done = was_done;
+            if (!p.forced && tok == p.eos) { p.done[crop] = 1; now_done = 1; }
+            keep = !now_done;
+        }
+        // stable compaction: exclusive prefix count of `keep` over the chunk
+        const unsigned long long mask = __ballot(keep);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(mask);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        int chunk_total = 0;
+        for (int q = 0; q < 8; ++q) chunk_total += wsum[q];
+        __syncthreads();   // everyone has read its own active[j] (above) and the counts: in-place writes may start
+        if (p.compact && keep) p.active[off + before] = crop;
+        if (tid == 0) base_s = off + chunk_total;   // tid 0 is wave 0: off == base_s here
+        live_total += chunk_total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (p.compact) *p.n_rows = live_total;
+        *p.host_rows = live_total;
+        __threadfence_system();
+    }
+}
+
+// ids = [start, pad, pad, ...]; nothing finished; the list holds every row
+__global__ void dec_init_kernel(int32_t* ids, int ld_ids, int32_t* done, int32_t* active, int* n_rows, int n, int start, int pad) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *n_rows = n;
+    if (b >= n) return;
+    done[b] = 0;
+    active[b] = b;
+    for (int c = 0; c < ld_ids; ++c) ids[(int64_t)b * ld_ids + c] = c == 0 ? start : pad;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- launchers
+// flags: 1 = fp16 output, 2 = exact GELU, 4 = split-K partial slabs (fp32, no bias)
+int vtd_launch_dec_gemm(const half_t* A, int lda, const half_t* W, const float* bias, void* out, int ldc, int64_t slab_stride, int M,
+                        const int* n_rows_dev, int N, int K, int ksplit, int flags, int wide, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || ksplit <= 0 || (K % (ksplit * 32)) || !n_rows_dev) return -2501;
+    if (ksplit > 1 && !(flags & DG_PARTIAL)) return -2502;
+    DecGemmParams p{A, W, bias, out, slab_stride, n_rows_dev, lda, ldc, M, N, K, ksplit, flags};
+    if (wide) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile
+        const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+        hipLaunchKernelGGL((dec_gemm_kernel<4, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        const dim3 grid((N + 31) / 32, (M + 63) / 64, ksplit);
+        hipLaunchKernelGGL((dec_gemm_kernel<4, 2>), grid, dim3(256), 0, s, p);
+    }
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_dec_ln(float* x, half_t* x16, const float* slabs, int64_t slab_stride, int nsplit, const float* bias, const float* gamma,
+                      const float* beta, const int* n_rows_dev, int M, int D, float eps, const float* embed, const float* pos, const int32_t* ids,
+                      const int32_t* active, int ld_ids, int col, int position, int vocab, hipStream_t s) {
+    if (M <= 0 || (D & 63) || D > 2048 || !n_rows_dev) return -2503;
+    DecLnParams p{x, x16, slabs, slab_stride, nsplit, bias, gamma, beta, n_rows_dev, M, D, eps, embed, pos, ids, active, ld_ids, col, position, vocab};
+    const dim3 grid((M + 3) / 4);
+    if (D <= 1024) hipLaunchKernelGGL(dec_ln_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(dec_ln_kernel<8>, grid, dim3(256), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_dec_attn(int self, const half_t* q, int ldq, half_t* kc, half_t* vc, int64_t crop_stride, int L, int D, half_t* out,
+                        const int32_t* active, const int* n_rows_dev, int M, int heads, hipStream_t s) {
+    if (L <= 0 || L > 16384 || heads * 64 != D || M <= 0) return -2504;
+    DecAttnParams p{q, ldq, kc, vc, crop_stride, L, D, out, active, n_rows_dev, M};
+    const size_t lds = (size_t)((L + 7) & ~7) * 4;
+    if (self) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(heads, M), dim3(64), lds, s, p);
+    else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(heads, M), dim3(64), lds, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_dec_argmax(const float* logits, int64_t ld, int V, int32_t* best_tok, const int* n_rows_dev, int M, hipStream_t s) {
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, V, best_tok, n_rows_dev, M);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_dec_advance(const int32_t* best_tok, int32_t* ids, int ld_ids, int col, int32_t* done, int32_t* active, int* n_rows_dev,
+                           int* host_rows, const int32_t* forced, int ld_forced, int forced_len, int eos, int pad, int compact, hipStream_t s) {
+    DecAdvanceParams p{best_tok, ids, done, active, n_rows_dev, host_rows, forced, ld_ids, col, ld_forced, forced_len, eos, pad, compact};
+    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(512), 0, s, p);
+    return -(int)hipGetLastError();
+}
+
+int vtd_launch_dec_init(int32_t* ids, int ld_ids, int32_t* done, int32_t* active, int* n_rows_dev, int n, int start, int pad, hipStream_t s) {
+    hipLaunchKernelGGL(dec_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, ld_ids, done, active, n_rows_dev, n, start, pad);
+    return -(int)hipGetLastError();
+}

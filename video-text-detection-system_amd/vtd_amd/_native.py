@@ -78,6 +78,13 @@ SIGNATURES = {
     "vtd_trocr_encode_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vtd_trocr_encode_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtd_trocr_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vtd_trocr_num_slots": (C.c_int, [C.c_void_p]),
+    "vtd_trocr_encode_crops_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_trocr_encode_pixels_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_trocr_generate_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vtd_trocr_last_steps": (C.c_int, [C.c_void_p]),
+    "vtd_trocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "vtd_trocr_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "vtd_trocr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vtd_trocr_encoder_tokens": (C.c_int, [C.c_void_p]),
     "vtd_trocr_logits_stride": (C.c_int, [C.c_void_p]),

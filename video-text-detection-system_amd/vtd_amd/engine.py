@@ -463,6 +463,10 @@ class TrOCREngine(_Tunable):
             raise
         self.tokens = int(self.lib.vtd_trocr_encoder_tokens(h))
         self.logits_stride = int(self.lib.vtd_trocr_logits_stride(h))
+        self.slots = int(self.lib.vtd_trocr_num_slots(h))
+        self._next_slot = 0
+        self._slot_ticket = [None] * self.slots     # the ticket whose encoder output lives in the slot and is not decoded yet
+        self._dec_stream = None
 
     def close(self):
         if getattr(self, "handle", None):
@@ -479,27 +483,34 @@ class TrOCREngine(_Tunable):
     def macs_per_crop(self):
         return int(self.lib.vtd_trocr_macs_per_crop(self.handle))
 
-    def encode_pixels(self, pixel_values):
-        """[n,3,S,S] float (any device): ViT encoder + cross-attention keys / values.  Call with the lock held."""
+    @property
+    def last_steps(self):
+        """Decoder steps the last generate call enqueued (it stops once every row has emitted </s>)."""
+        return int(self.lib.vtd_trocr_last_steps(self.handle))
+
+    def encode_pixels(self, pixel_values, slot=0):
+        """[n,3,S,S] float (any device): ViT encoder + cross-attention keys / values into `slot`.  Call with the lock held."""
         s = self.spec.image_size
         if not torch.is_tensor(pixel_values) or pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (3, s, s):
             raise ValueError(f"pixel_values must be [n,3,{s},{s}] float")
         x = pixel_values.to("cuda", torch.float32).contiguous()
-        _native.check(self.lib.vtd_trocr_encode_pixels(self.handle, C.c_void_p(x.data_ptr()), x.shape[0], _stream_ptr()), "vtd_trocr_encode_pixels")
+        _native.check(self.lib.vtd_trocr_encode_pixels_slot(self.handle, slot, C.c_void_p(x.data_ptr()), x.shape[0], _stream_ptr()),
+                      "vtd_trocr_encode_pixels")
         self._keep = x
         return x.shape[0]
 
-    def encode_crops(self, frames, boxes):
-        """boxes [(frame, x1, y1, x2, y2), ...] of a DeviceFrames batch.  Call with the lock held."""
+    def encode_crops(self, frames, boxes, slot=0):
+        """boxes [(frame, x1, y1, x2, y2), ...] of a DeviceFrames batch into `slot`.  Call with the lock held."""
         b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
         frames.wait_ready()
-        _native.check(self.lib.vtd_trocr_encode_crops(self.handle, C.c_void_p(frames.tensor.data_ptr()), frames.n, frames.height, frames.width,
-                                                      b.ctypes.data, b.shape[0], _stream_ptr()), "vtd_trocr_encode_crops")
+        _native.check(self.lib.vtd_trocr_encode_crops_slot(self.handle, slot, C.c_void_p(frames.tensor.data_ptr()), frames.n, frames.height,
+                                                           frames.width, b.ctypes.data, b.shape[0], _stream_ptr()), "vtd_trocr_encode_crops")
         self._keep = (b, frames)
         return b.shape[0]
 
-    def generate_current(self, n, max_length=None, forced=None, want_logits=False):
-        """Greedy decode of the n crops encoded last.  Returns (ids [n,max_length] int32 cpu tensor, logits or None)."""
+    def _enqueue_generate(self, n, slot, max_length=None, forced=None, want_logits=False):
+        """Greedy decode of the n crops encoded into `slot`, on the CURRENT stream.  Returns device tensors (ids, logits | None); the
+        call itself returns once all but the last two decoder steps have run (the handle paces itself two steps behind the GPU)."""
         max_length = max_length or self.spec.max_length
         ids = torch.empty((n, max_length), dtype=torch.int32, device="cuda")
         logits = torch.zeros((n, max_length - 1, self.logits_stride), dtype=torch.float32, device="cuda") if want_logits else None
@@ -507,9 +518,15 @@ class TrOCREngine(_Tunable):
         if forced is not None:
             fdev = torch.as_tensor(np.asarray(forced), dtype=torch.int32).to("cuda").contiguous()
             flen = fdev.shape[1]
-        _native.check(self.lib.vtd_trocr_generate(self.handle, n, max_length, C.c_void_p(fdev.data_ptr()) if fdev is not None else None, flen,
-                                                  C.c_void_p(ids.data_ptr()), C.c_void_p(logits.data_ptr()) if logits is not None else None,
-                                                  _stream_ptr()), "vtd_trocr_generate")
+        _native.check(self.lib.vtd_trocr_generate_slot(self.handle, slot, n, max_length, C.c_void_p(fdev.data_ptr()) if fdev is not None else None,
+                                                       flen, C.c_void_p(ids.data_ptr()), C.c_void_p(logits.data_ptr()) if logits is not None else None,
+                                                       _stream_ptr()), "vtd_trocr_generate")
+        self._keep_gen = (fdev,)
+        return ids, logits
+
+    def generate_current(self, n, max_length=None, forced=None, want_logits=False, slot=0):
+        """Greedy decode of the n crops encoded last into `slot`.  Returns (ids [n,max_length] int32 cpu tensor, logits or None)."""
+        ids, logits = self._enqueue_generate(n, slot, max_length, forced, want_logits)
         out = ids.cpu()
         return out, (logits[..., :self.spec.vocab_size].cpu() if logits is not None else None)
 
@@ -530,6 +547,69 @@ class TrOCREngine(_Tunable):
                 n = self.encode_crops(frames, boxes[i:i + self.max_crops])
                 outs.append(self.generate_current(n, **kw)[0])
         return torch.cat(outs)
+
+    # ---- pipelined use: the encoder pass of batch i+1 (MFMA-bound) overlaps the decode of batch i (latency- / HBM-bound) -------------
+    def decode_stream(self):
+        if self._dec_stream is None:
+            self._dec_stream = torch.cuda.Stream(priority=-1)   # short dependent kernels: dispatched ahead of the encoder's wide launches
+        return self._dec_stream
+
+    def submit_crops(self, frames, boxes):
+        """Enqueue the encoder pass (crop -> processor -> ViT -> cross-attention keys / values) for `boxes` on the caller's stream, in
+        chunks of max_crops, alternating between the handle's slots; nothing synchronises.  Returns a ticket for ``finish``.  A
+        chunk whose slot still holds an undecoded pass decodes that pass first (its ids stay with its ticket)."""
+        chunks = []
+        with self.lock:
+            for i in range(0, len(boxes), self.max_crops):
+                slot = self._next_slot
+                self._next_slot = (slot + 1) % self.slots
+                if self._slot_ticket[slot] is not None:
+                    self._decode(self._slot_ticket[slot])
+                chunk = {"slot": slot, "n": 0, "ids": None, "frames": frames}
+                chunk["n"] = self.encode_crops(frames, boxes[i:i + self.max_crops], slot)
+                chunk["encoded"] = torch.cuda.Event()
+                chunk["encoded"].record()
+                self._slot_ticket[slot] = chunk
+                chunks.append(chunk)
+        return chunks
+
+    def _decode(self, chunk):
+        """Greedy decode of one encoded chunk on the decode stream + asynchronous copy of the ids to pinned memory (lock held)."""
+        if chunk["ids"] is not None:
+            return
+        with torch.cuda.stream(self.decode_stream()):
+            ids, _ = self._enqueue_generate(chunk["n"], chunk["slot"])
+            host = PINNED.take(tuple(ids.shape))
+            host.copy_(ids, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        chunk.update(ids=ids, host=host, event=ev)
+        if self._slot_ticket[chunk["slot"]] is chunk:
+            self._slot_ticket[chunk["slot"]] = None
+
+    def finish(self, chunks):
+        """ids [n, max_length] int32 (cpu) of a ticket: decodes what is still only encoded, then waits for the copies."""
+        outs = []
+        with self.lock:
+            for chunk in chunks:
+                self._decode(chunk)
+        for chunk in chunks:
+            chunk["event"].synchronize()
+            outs.append(chunk["host"].clone())
+            PINNED.release(chunk["host"])
+            chunk["frames"] = None
+        return torch.cat(outs) if outs else torch.empty((0, self.spec.max_length), dtype=torch.int32)
+
+    def set_profiling(self, mode):
+        _native.check(self.lib.vtd_trocr_set_profiling(self.handle, int(mode)), "vtd_trocr_set_profiling")
+
+    def profile(self):
+        """(total ms, launches, summed row counts) of the bracketed cross-attention launches since the last call."""
+        ms, calls, rows = C.c_double(), C.c_int64(), C.c_int64()
+        stream = self._dec_stream if self._dec_stream is not None else torch.cuda.current_stream()
+        _native.check(self.lib.vtd_trocr_get_profile(self.handle, C.byref(ms), C.byref(calls), C.byref(rows), C.c_void_p(stream.cuda_stream)),
+                      "vtd_trocr_get_profile")
+        return ms.value, calls.value, rows.value
 
     def read_tap(self, name, n):
         s = self.spec

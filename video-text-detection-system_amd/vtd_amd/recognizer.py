@@ -224,9 +224,10 @@ class TextRecognizer:
     def submit_boxes(self, frames: DeviceFrames, boxes):
         if len(boxes) == 0:
             return None
-        if self.use_transformer:  # generate() synchronises between steps anyway: the ticket already holds the strings
-            ids = self.model.recognize_boxes_ids(frames, [tuple(int(v) for v in b) for b in boxes])
-            return {"transformer": [{"text": self.model.decode_ids(s), "confidence": 0.95} for s in ids]}
+        if self.use_transformer:
+            # only the encoder pass is enqueued here (asynchronous); the decode runs when the ticket is finished -- by then the NEXT
+            # batch's encoder pass is already queued on this stream and overlaps it (engine.TrOCREngine.submit_crops / finish)
+            return {"transformer": self.model.engine().submit_crops(frames, [tuple(int(v) for v in b) for b in boxes])}
         eng = self.model.engine()
         if getattr(self, "_id2char_dev", None) is None:
             self._id2char_dev = torch.tensor(self._id2char, dtype=torch.int32, device="cuda")
@@ -237,7 +238,9 @@ class TextRecognizer:
         if not tickets:
             return []
         if isinstance(tickets, dict) and "transformer" in tickets:
-            return tickets["transformer"]
+            from .engine import trim_generated
+            ids = trim_generated(self.model.engine().finish(tickets["transformer"]), self.model.spec)
+            return [{"text": self.model.decode_ids(s), "confidence": 0.95} for s in ids]
         eng = self.model.engine()
         out = []
         for t in tickets:
