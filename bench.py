@@ -407,23 +407,38 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)) + 1)   # same count on every rank (elapsed is the MAX)
-        clk0 = read_sclk_mhz()
+        import threading
+        clk0, samples, stop = read_sclk_mhz(), [], threading.Event()
+
+        def sampler():   # the clocks DURING the leg (a read after it finds the card already idling at its lowest level)
+            while not stop.wait(0.25):
+                samples.append(read_sclk_mhz())
+
+        th = threading.Thread(target=sampler, daemon=True)
         barrier()
+        th.start()
         t1 = time.perf_counter()
         for _ in range(n_sus):
             step()
         drain()
         barrier()
         dt = time.perf_counter() - t1
+        stop.set()
+        th.join(timeout=2)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         sustained = {"seconds": round(dt, 3), "steps": n_sus, "value": round(world * B * n_sus / dt, 2), "unit": "frames/s",
                      "ms_per_step": round(dt / n_sus * 1e3, 3), "vs_timed_region": round((world * B * n_sus / dt) / (world * B * args.steps / elapsed), 4),
-                     "sclk_mhz_before": clk0, "sclk_mhz_after": read_sclk_mhz(),
-                     "what": "same steps back to back, started right after the timed region; sclk = current level of every card the host "
-                             "exposes under /sys/class/drm (ours is among them), read just before and just after the leg"}
+                     "sclk_mhz_before": clk0,
+                     "sclk_mhz_during": {"samples": len(samples),
+                                         "min": [min(v) for v in zip(*samples)] if samples else None,
+                                         "median": [sorted(v)[len(v) // 2] for v in zip(*samples)] if samples else None,
+                                         "max": [max(v) for v in zip(*samples)] if samples else None},
+                     "what": "same steps back to back, started right after the timed region; sclk = current level (pp_dpm_sclk) of every "
+                             "card the host exposes under /sys/class/drm (ours is among them; the others belong to other tenants), read just "
+                             "before the leg and every 0.25 s during it"}
 
     cpu_baseline = None
     if rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:

@@ -31,7 +31,8 @@ def sources():
 def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    headers = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +   # .inc: textually included graph code
+               glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     newest_hdr = max(os.path.getmtime(h) for h in headers)
     objs, procs = [], []
     for src in sources():

@@ -11,8 +11,8 @@
 //    workgroups writes fp32 partial slabs that the NEXT kernel of the chain (the LayerNorm) sums -- the launch-boundary combine of
 //    cdna_hip_programming.md section 5 ("Projection GEMM at M = 256", item 2): no atomics, fixed summation order, bitwise repeatable.
 //  * dec_ln: residual + bias + split-K slabs -> LayerNorm -> fp32 stream + fp16 GEMM input, one wave per row.
-//  * dec_self_attn / dec_cross_attn: one wave per (row, head), eight lanes per 128-byte key / value row; the self-attention wave also
-//    files the step's new key / value into the crop's cache rows.
+//  * dec_attn<SELF | CROSS>: four waves per (row, head), eight lanes per 128-byte key / value row, three rounds of 32 keys in flight;
+//    the self-attention workgroup also files the step's new key / value into the crop's cache rows.
 //  * dec_argmax + dec_advance: greedy token, GenerationMixin's </s> / <pad> bookkeeping, and the COMPACTION of the row list: rows that
 //    emitted </s> leave `active[]`, so every later kernel runs on the live rows only (per-row buffers are indexed by list position j,
 //    caches / ids / encoder keys by crop = active[j]).  The live count goes to device memory (exact, read by every kernel) and to
@@ -215,14 +215,20 @@ struct DecAttnParams {
     int M;
 };
 
+// Workgroup = four waves per (row, head).  The first version gave a (row, head) to ONE wave that walked its keys eight at a time:
+// 73 dependent load -> use rounds per pass for the 577 encoder tokens, i.e. ~100 us per launch however few rows were live (measured:
+// 110 us at 64 live rows, 0.17 of the HBM rate).  Now the 256 threads cover 32 keys per round (eight lanes per 128-byte row), three
+// rounds are in flight per thread, the score pass and the value pass are each 6 dependent rounds for 577 tokens, and the partial
+// sums meet through LDS in a fixed order (bitwise repeatable).
 template <bool SELF>
-__global__ __launch_bounds__(64) void dec_attn_kernel(DecAttnParams p) {
+__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* pr = (float*)smem;  // [L rounded up to 8]
-    const int j = blockIdx.y, head = blockIdx.x, lane = threadIdx.x;
+    float* pr = (float*)smem;              // [L rounded up to 32] scores, then probabilities
+    float* red = pr + ((p.L + 31) & ~31);  // [4 waves][64] partial outputs; [0..7] block reductions
+    const int j = blockIdx.y, head = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (j >= min(*p.n_rows, p.M)) return;
     const int crop = p.active[j];
-    const int sub = lane >> 3, seg = lane & 7;   // key within a group of eight, 16-byte segment of the row
+    const int sub = tid >> 3, seg = tid & 7;   // key within a round of 32, 16-byte segment of the row
     const half_t* qrow = p.q + (int64_t)j * p.ldq + head * 64 + seg * 8;
     const half8 qv = *(const half8*)qrow;
     float qf[8];
@@ -240,56 +246,89 @@ __global__ __launch_bounds__(64) void dec_attn_kernel(DecAttnParams p) {
             *(half8*)(vb + (int64_t)(L - 1) * D) = vnew;
         }
     }
+    constexpr int U = 3;   // rounds in flight per thread
+    // ---- scores
     float mx = -INFINITY;
-    for (int k0 = 0; k0 < L; k0 += 8) {
-        const int key = k0 + sub;
-        float s = 0.f;
-        if (key < L) {
-            const half8 kv = (SELF && key == L - 1) ? knew : *(const half8*)(kb + (int64_t)key * D);
+    for (int k0 = 0; k0 < L; k0 += 32 * U) {
+        half8 kv[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[e];
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 32 * u + sub;
+            kv[u] = knew;
+            if (key < L && !(SELF && key == L - 1)) kv[u] = *(const half8*)(kb + (int64_t)key * D);
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s = key < L ? s : -INFINITY;
-        if (seg == 0) pr[key] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 32 * u + sub;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[u][e];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (key < L) {
+                if (seg == 0) pr[key] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[w] = mx;
     __syncthreads();
-    const int lpad = (L + 7) & ~7;
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // ---- softmax numerators and their sum (fixed order: thread strides, wave shuffles, waves 0..3)
     float sum = 0.f;
-    for (int key = lane; key < lpad; key += 64) {
-        const float e = key < L ? expf(pr[key] - mx) : 0.f;
+    for (int key = tid; key < L; key += 256) {
+        const float e = expf(pr[key] - mx);
         pr[key] = e;
         sum += e;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + w] = sum;
     __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    // ---- weighted values
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < L; k0 += 8) {
-        const int key = k0 + sub;
-        if (key < L) {
-            const float pk = pr[key];
-            const half8 vv = (SELF && key == L - 1) ? vnew : *(const half8*)(vb + (int64_t)key * D);
+    for (int k0 = 0; k0 < L; k0 += 32 * U) {
+        half8 vv[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += pk * (float)vv[e];
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 32 * u + sub;
+            vv[u] = vnew;
+            if (key < L && !(SELF && key == L - 1)) vv[u] = *(const half8*)(vb + (int64_t)key * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 32 * u + sub;
+            if (key < L) {
+                const float pk = pr[key];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += pk * (float)vv[u][e];
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 8; ++e) {   // the eight key lanes of a wave that share a segment
         acc[e] += __shfl_xor(acc[e], 8);
         acc[e] += __shfl_xor(acc[e], 16);
         acc[e] += __shfl_xor(acc[e], 32);
     }
-    if (sub == 0) {
+    __syncthreads();   // red[0..7] have been read by everyone
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w * 64 + lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 8) {
         half8 hv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hv[e] = (half_t)(acc[e] / sum);
-        *(half8*)(p.out + (int64_t)j * D + head * 64 + seg * 8) = hv;
+        for (int e = 0; e < 8; ++e) {
+            const int c = tid * 8 + e;
+            hv[e] = (half_t)(((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) / sum);
+        }
+        *(half8*)(p.out + (int64_t)j * D + head * 64 + tid * 8) = hv;
     }
 }
 
@@ -432,9 +471,9 @@ int vtd_launch_dec_attn(int self, const half_t* q, int ldq, half_t* kc, half_t* 
                         const int32_t* active, const int* n_rows_dev, int M, int heads, hipStream_t s) {
     if (L <= 0 || L > 16384 || heads * 64 != D || M <= 0) return -2504;
     DecAttnParams p{q, ldq, kc, vc, crop_stride, L, D, out, active, n_rows_dev, M};
-    const size_t lds = (size_t)((L + 7) & ~7) * 4;
-    if (self) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(heads, M), dim3(64), lds, s, p);
-    else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(heads, M), dim3(64), lds, s, p);
+    const size_t lds = (size_t)(((L + 31) & ~31) + 256) * 4;
+    if (self) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(heads, M), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(heads, M), dim3(256), lds, s, p);
     return -(int)hipGetLastError();
 }
 
