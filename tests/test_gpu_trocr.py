@@ -247,3 +247,45 @@ def test_pipelined_tickets_equal_the_synchronous_calls(base):
     got2 = eng.finish(t2).numpy()
     for g, w in zip((got0, got1, got2), want):
         assert np.array_equal(g, w)
+
+
+def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golden_dir, monkeypatch):
+    """dense_gemm.hip (256 x 256 tiles, LDS-DMA ring three stages ahead behind counted waits, two wave groups one barrier interval
+    apart) forced onto every dense layer of the encoder pass it fits (VTD_DENSE_GEMM=1; by default it takes them from ~80 crops up):
+    encoder states and first-step logits against the transformers golden at the implicit-GEMM path's tolerances, greedy ids of the
+    margin-selected crops identical, the two GEMM paths within a fraction of that tolerance of each other, and -- a staged-operand
+    kernel that reads a buffer one barrier early is wrong only now and then -- eight runs under a concurrent stream bit-identical."""
+    from vtd_amd.engine import DeviceFrames, trim_generated
+    eng, sd = base
+    man = json.load(open(os.path.join(golden_dir, "trocr_manifest.json")))["base"]
+    g = np.load(os.path.join(golden_dir, "trocr_base.npz"))
+    crops = [synth.glyph_crop(r["seed"]) for r in man["rows"]]
+    frames, boxes = _crops_in_frames(crops)
+    dev = DeviceFrames(frames)
+
+    def run():
+        ids = eng.generate_crops(dev, boxes)
+        return trim_generated(ids, BASE_PRINTED), eng.read_tap("encoder", len(crops))
+
+    monkeypatch.setenv("VTD_DENSE_GEMM", "0")
+    ids_ig, enc_ig = run()
+    monkeypatch.setenv("VTD_DENSE_GEMM", "1")
+    ids_dg, enc_dg = run()
+    assert ids_dg == [r["ids"] for r in man["rows"]] == ids_ig
+    err = float(np.abs(enc_dg[0, 0] - g["enc_cls"]).max())
+    between = float(np.abs(enc_dg - enc_ig).max())
+    print("dense-GEMM encoder: cls err vs golden", err, "max |dense - implicit|", between)
+    assert err <= 2e-2 and float(np.abs(enc_dg[0, [1, 100, 576]] - g["enc_rows"]).max()) <= 2e-2
+    assert between <= 1e-2
+    # repeatability under load: a second stream keeps the CUs and the memory system busy while the encoder pass runs
+    side = torch.cuda.Stream()
+    noise = torch.randn(4096, 4096, device="cuda")
+    for _ in range(8):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                noise = noise * 1.0001 + 0.5
+        with eng.lock:
+            eng.encode_crops(dev, boxes)
+        again = eng.read_tap("encoder", len(crops))
+        assert np.array_equal(again, enc_dg)
+    side.synchronize()

@@ -550,6 +550,10 @@ class TrOCREngine(_Tunable):
 
     # ---- pipelined use: the encoder pass of batch i+1 (MFMA-bound) overlaps the decode of batch i (latency- / HBM-bound) -------------
     def decode_stream(self):
+        """The stream the pipelined decodes run on.  VTD_TROCR_DEC_STREAM=0: the caller's stream (encoder pass of ticket i+1 and decode
+        of ticket i then run back to back instead of side by side -- the A/B switch for the overlap)."""
+        if os.environ.get("VTD_TROCR_DEC_STREAM", "1") == "0":
+            return torch.cuda.current_stream()
         if self._dec_stream is None:
             self._dec_stream = torch.cuda.Stream(priority=-1)   # short dependent kernels: dispatched ahead of the encoder's wide launches
         return self._dec_stream
