@@ -17,6 +17,8 @@
 //     restaged only after a barrier that every reader reached with its fragments consumed by issued MFMAs;
 //   * epilogue straight from the accumulators: weight rows are permuted on the source side so that a lane owns 8 consecutive output
 //     channels -> bias, GELU, one 16-byte store (fp16) or two (fp32) per row and channel group.
+#include <algorithm>
+#include <cstdlib>
 #include "vtd_common.h"
 
 namespace {
@@ -31,10 +33,24 @@ struct DenseGemmParams {
     const float* bias;   // [>= N rounded up to 8]
     void* out;           // fp16 / fp32 [M][ldc]
     int M, N, K, lda, ldc, w_rows, tiles_n, flags;   // flags: EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU
+    int tiles_m, gn, blocks_n;                       // tile order: super-blocks of DGM_GM x gn tiles per XCD (gn = 0: row-major runs)
+    int nvb;                                         // virtual block ids to walk (tiles incl. the padding of the last super-block row)
 };
+constexpr int DGM_GM = 8;
 
 template <int N>
 __device__ __forceinline__ void dgm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, branch-free: one rcp, one
+// exp, five fused multiply-adds) -- three orders of magnitude below the fp16 rounding of the value it produces; libdevice's erff
+// expands to a two-branch polynomial whose eight interleaved copies per row do not fit beside 128 accumulators.
+__device__ __forceinline__ float dgm_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 __device__ __forceinline__ void dgm_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -42,46 +58,71 @@ __device__ __forceinline__ void dgm_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+struct DgmTile {
+    int a[2], b[2];   // element offsets of this lane's chunk slots from p.A / p.W (both operands stay below 2^31 elements: launcher)
+    int m0, n0;
+};
+
+// virtual block id -> tile (false: padding of the last super-block row / past the end)
+__device__ __forceinline__ bool dgm_locate(const DenseGemmParams& p, int vb, int& tm, int& tn) {
+    if (p.gn > 0) {
+        // Super-block order: virtual block ids that are congruent mod 8 are worked by one XCD (one L2): XCD x takes super-blocks x, x + 8,
+        // ... and its CUs work through a super-block of DGM_GM x gn tiles together: DGM_GM A panels + gn W panels (~0.4 MB each at
+        // K = 768) serve 8 gn tiles out of that L2, instead of one fresh W panel per tile when N K exceeds the L2.
+        const int xcd = vb & 7, local = vb >> 3, per = DGM_GM * p.gn;
+        const int blk = (local / per) * 8 + xcd, idx = local - (local / per) * per;
+        const int bm = blk / p.blocks_n, bn = blk - bm * p.blocks_n;
+        tm = bm * DGM_GM + idx / p.gn;
+        tn = bn * p.gn + idx % p.gn;
+        return tm < p.tiles_m;
+    }
+    const int total = p.tiles_m * p.tiles_n;   // row-major runs: XCD x owns the x-th eighth of the tiles
+    const int q = total >> 3, r8 = total & 7, xcd = vb & 7, local = vb >> 3;
+    const int cnt = q + (xcd < r8 ? 1 : 0);
+    if (local >= cnt) return false;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    tm = tile / p.tiles_n;
+    tn = tile - tm * p.tiles_n;
+    return true;
+}
+
+template <bool GELU>
 __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dgm_smem[];
-    // ---- XCD-aware tile order (bijective for any grid): an XCD sweeps a contiguous run of tiles, N fastest, so the 256-row A panel
-    // of a tile row is fetched from HBM once per XCD
-    const int nblk = gridDim.x, b = blockIdx.x;
-    const int q = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * DGM_BM, n0 = tn * DGM_BN;
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
+    const int G = gridDim.x;   // a multiple of 8: a workgroup's virtual block ids b, b + G, ... stay on its XCD
 
     // ---- loader: wave w brings pieces w and w + 8 (16 rows x 64 bytes each) of the A tile and of the B tile of every stage.
     // Lane l of a piece lands at LDS row 16 piece + (l >> 2), physical chunk l & 3, and therefore fetches logical chunk
     // (l & 3) ^ ((row >> 2) & 3) of that row.
-    const half_t* asrc[2];
-    const half_t* bsrc[2];
+    auto make_tile = [&](int tm, int tn, DgmTile& t) {
+        t.m0 = tm * DGM_BM;
+        t.n0 = tn * DGM_BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (w + 8 * i) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        int m = m0 + row;
-        m = m < p.M ? m : p.M - 1;                       // rows past the end re-read the last row (never written)
-        asrc[i] = p.A + (int64_t)m * p.lda + chunk * 8;
-        // B row `row` of the tile feeds MFMA row (row & 15) of fragment (row >> 4) & 3 of wave column row >> 6; it is fed with the
-        // weights of the channel that makes a lane's accumulators 8 consecutive channels (see the epilogue)
-        const int x = row & 63, blk = x >> 4, rr = x & 15;
-        int n = n0 + (row - x) + 32 * (blk >> 1) + 8 * (rr >> 2) + 4 * (blk & 1) + (rr & 3);
-        n = n < p.w_rows ? n : p.w_rows - 1;
-        bsrc[i] = p.W + (int64_t)n * p.K + chunk * 8;
-    }
-    auto issue = [&](int stage) {   // stage index s: K offset 32 s, ring slot s & 3
-        char* base = dgm_smem + (stage & (DGM_NST - 1)) * DGM_STAGE;
+        for (int i = 0; i < 2; ++i) {
+            const int row = (w + 8 * i) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            int m = t.m0 + row;
+            m = m < p.M ? m : p.M - 1;                       // rows past the end re-read the last row (never written)
+            t.a[i] = m * p.lda + chunk * 8;
+            // B row `row` of the tile feeds MFMA row (row & 15) of fragment (row >> 4) & 3 of wave column row >> 6; it is fed with the
+            // weights of the channel that makes a lane's accumulators 8 consecutive channels (see the epilogue)
+            const int x = row & 63, blk = x >> 4, rr = x & 15;
+            int n = t.n0 + (row - x) + 32 * (blk >> 1) + 8 * (rr >> 2) + 4 * (blk & 1) + (rr & 3);
+            n = n < p.w_rows ? n : p.w_rows - 1;
+            t.b[i] = n * p.K + chunk * 8;
+        }
+    };
+    auto issue = [&](const DgmTile& t, int stage, int slot) {   // K offset 32 stage of tile t into ring slot `slot`
+        char* base = dgm_smem + slot * DGM_STAGE;
         const int k = stage * DGM_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(asrc[i] + k), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.A + (t.a[i] + k)), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(bsrc[i] + k), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.W + (t.b[i] + k)), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
     };
 
     // ---- fragment read offsets (bytes inside a stage): A rows wm * 128 + 16 i + fr, B rows wn * 64 + 16 j + fr, logical chunk fq
@@ -98,76 +139,119 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
     }
 
     floatx4 acc[8][4];
+    // epilogue from registers: lane (fr, fq) holds row m0 + wm * 128 + 16 i + fr, channels n0 + wn * 64 + 32 jp + 8 fq + 0..7
+    // (acc[i][2 jp][0..3] then acc[i][2 jp + 1][0..3], by the row permutation of the loader)
+    auto epilogue = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int jp = 0; jp < 2; ++jp) {
+            const int n = n0 + wn * 64 + jp * 32 + fq * 8;
+            if (n >= p.N) continue;
+            const floatx4 b0 = *(const floatx4*)(p.bias + n), b1 = *(const floatx4*)(p.bias + n + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + fr;
+                if (m >= p.M) continue;
+                floatx4 v0 = acc[i][2 * jp] + b0, v1 = acc[i][2 * jp + 1] + b1;
+                if constexpr (GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = dgm_gelu(v0[e]); v1[e] = dgm_gelu(v1[e]); }
+                }
+                if (p.flags & EPI_OUT_F16) {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (half_t)v0[e]; h[4 + e] = (half_t)v1[e]; }
+                    *(half8*)((half_t*)p.out + (int64_t)m * p.ldc + n) = h;
+                } else {
+                    float* o = (float*)p.out + (int64_t)m * p.ldc + n;
+                    *(floatx4*)o = v0;
+                    *(floatx4*)(o + 4) = v1;
+                }
+                if constexpr (GELU) __builtin_amdgcn_sched_barrier(0);   // one row's GELU at a time (register budget)
+            }
+        }
+    };
+
+    // ---- this workgroup's tiles: virtual blocks b, b + G, ...  (persistent: the operand ring runs on ACROSS tiles, so a tile's prologue
+    // latency and its epilogue hide under the neighbouring tiles' stages)
+    int vb = blockIdx.x, tm = 0, tn = 0;
+    while (vb < p.nvb && !dgm_locate(p, vb, tm, tn)) vb += G;
+    if (vb >= p.nvb) return;   // uniform over the workgroup, before any barrier
+    DgmTile cur, nxt;
+    make_tile(tm, tn, cur);
+    nxt = cur;
 
     const int S = p.K / DGM_BK;   // >= 4 (launcher)
-    issue(0);
-    issue(1);
-    issue(2);
+    int g = 0;                    // global stage counter of this workgroup: stage s of its t-th tile is g = t S + s, ring slot g & 3
+    issue(cur, 0, 0);
+    issue(cur, 1, 1);
+    issue(cur, 2, 2);
     dgm_wait_vmcnt<8>();          // this wave's pieces of stage 0 have landed (stages 1, 2 stay in flight)
     dgm_barrier();                // hw barrier 0: stage 0 is published
     if (wm == 1) dgm_barrier();   // group 1 runs one interval behind group 0 from here on
 
     half8 af[8], bf[4];
-    for (int s = 0; s < S; ++s) {
-        // ---- interval R_s: fragments of stage s.  (Published: every wave waited for its stage-s pieces at the end of its R_{s-1}
-        // -- or in the prologue -- and has passed a barrier since; this wave is at least one barrier past the last of those waits.)
-        const char* st = dgm_smem + (s & (DGM_NST - 1)) * DGM_STAGE;
+    bool have_prev = false;
+    int prev_m0 = 0, prev_n0 = 0;
+    for (;;) {
+        int vb2 = vb + G, tm2 = 0, tn2 = 0;
+        while (vb2 < p.nvb && !dgm_locate(p, vb2, tm2, tn2)) vb2 += G;
+        const bool has_next = vb2 < p.nvb;
+        if (has_next) make_tile(tm2, tn2, nxt);
+        for (int s = 0; s < S; ++s, ++g) {
+            // ---- interval R: fragments of stage g.  (Published: every wave waited for its pieces of this stage at the end of its
+            // previous R interval -- or in the prologue -- and has passed a barrier since.)
+            const char* st = dgm_smem + (g & (DGM_NST - 1)) * DGM_STAGE;
+            // Stage g + 1 must have landed before the barrier that ends this interval; stage g + 2 (issued in the previous MM) may stay
+            // in flight.  Loads return in order, so "at most 4 outstanding" means stage g + 1 is in.
+            if (s == 0 && have_prev) {
+                // first stage of a new tile: the previous tile's accumulators leave from here, while the other wave of this SIMD
+                // multiplies.  The wait comes BEFORE the stores (they share the counter and retire in any order: behind them the same
+                // wait would also sit out their acknowledgements), the fragment reads after them (their registers are free until then).
+                dgm_wait_vmcnt<4>();
+                epilogue(prev_m0, prev_n0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[j]);
+                for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[j]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const half8*)(st + a_off[i]);
-        // stage s + 1 must have landed before the barrier that ends this interval; stage s + 2 (issued in MM_{s-1}) may stay in flight
-        if (s + 2 < S) dgm_wait_vmcnt<4>(); else dgm_wait_vmcnt<0>();
-        dgm_barrier();
-        // ---- interval MM_s: restage ring slot (s + 3) & 3 = (s - 1) & 3.  Its last readers were the R_{s-1} intervals: this group's
-        // ended two barriers ago, the other group's one barrier ago at the latest, and every wave reached that barrier only after its
-        // MFMAs of MM_{s-1} -- which consume those fragments -- had been issued, i.e. after the reads had returned.
-        if (s + 3 < S) issue(s + 3);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        dgm_barrier();
-    }
-    if (wm == 0) dgm_barrier();   // group 0 pays back group 1's extra barrier (every wave executes 2 S + 2 barriers)
-
-    // ---- epilogue from registers: lane (fr, fq) holds row m0 + wm * 128 + 16 i + fr, channels n0 + wn * 64 + 32 jp + 8 fq + 0..7
-    // (acc[i][2 jp][0..3] then acc[i][2 jp + 1][0..3], by the row permutation of the loader)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-        const int n = n0 + wn * 64 + jp * 32 + fq * 8;
-        if (n >= p.N) continue;
-        const floatx4 b0 = *(const floatx4*)(p.bias + n), b1 = *(const floatx4*)(p.bias + n + 4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wm * 128 + i * 16 + fr;
-            if (m >= p.M) continue;
-            floatx4 v0 = acc[i][2 * jp] + b0, v1 = acc[i][2 * jp + 1] + b1;
-            if (p.flags & EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v0[e] = 0.5f * v0[e] * (1.0f + erff(v0[e] * 0.70710678118654752f));
-                    v1[e] = 0.5f * v1[e] * (1.0f + erff(v1[e] * 0.70710678118654752f));
-                }
-            }
-            if (p.flags & EPI_OUT_F16) {
-                half8 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = (half_t)v0[e]; h[4 + e] = (half_t)v1[e]; }
-                *(half8*)((half_t*)p.out + (int64_t)m * p.ldc + n) = h;
+                for (int i = 0; i < 8; ++i) af[i] = *(const half8*)(st + a_off[i]);
             } else {
-                float* o = (float*)p.out + (int64_t)m * p.ldc + n;
-                *(floatx4*)o = v0;
-                *(floatx4*)(o + 4) = v1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = *(const half8*)(st + a_off[i]);
+                if (s + 2 < S || has_next) dgm_wait_vmcnt<4>(); else dgm_wait_vmcnt<0>();
             }
+            dgm_barrier();
+            // ---- interval MM: restage ring slot (g + 3) & 3 = (g - 1) & 3.  Its last readers were the R intervals of stage g - 1: this
+            // group's ended two barriers ago, the other group's one barrier ago at the latest, and every wave reached that barrier only
+            // after its MFMAs of the MM interval of stage g - 1 -- which consume those fragments -- had been issued.
+            if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1));
+            else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1));
+            __builtin_amdgcn_s_setprio(1);
+            if (s == 0) {   // a tile's first stage starts its accumulators
+                const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            dgm_barrier();
         }
+        have_prev = true;
+        prev_m0 = cur.m0;
+        prev_n0 = cur.n0;
+        if (!has_next) break;
+        cur = nxt;
+        vb = vb2;
     }
+    if (wm == 0) dgm_barrier();   // group 0 pays back group 1's extra barrier (every wave executes the same number of barriers)
+    epilogue(prev_m0, prev_n0);
 }
 
 }  // namespace
@@ -184,15 +268,34 @@ bool vtd_dense_gemm_supported(int64_t M, int N, int K, int lda, int ldc, int fla
 int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows, const float* bias, void* out, int ldc, int64_t M, int N, int K,
                           int flags, hipStream_t stream) {
     if (M < 256 || N < 256 || (N & 7) || (K & 31) || K < 128 || (lda & 7) || (ldc & 7) || M > 0x7fffffff ||
-        !(flags & (EPI_OUT_F16 | EPI_OUT_F32)) || (flags & ~(EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU)))
+        !(flags & (EPI_OUT_F16 | EPI_OUT_F32)) || (flags & ~(EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU)) ||
+        M * (int64_t)lda >= 0x7fffffff || (int64_t)w_rows * K >= 0x7fffffff)
         return -2601;
-    DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags};
+    DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags, 0, 0, 0, 0};
+    p.tiles_m = (int)((M + DGM_BM - 1) / DGM_BM);
+    int order = 1;
+    if (const char* e = std::getenv("VTD_DGM_ORDER")) order = std::atoi(e);   // 0: row-major runs per XCD (A/B measurements)
+    if (order) {
+        for (int g = 4; g >= 1; --g)
+            if (p.tiles_n % g == 0) { p.gn = g; break; }
+        p.blocks_n = p.tiles_n / p.gn;
+    }
     static bool attr = false;
     if (!attr) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         attr = true;
     }
-    const int64_t tiles = ((M + DGM_BM - 1) / DGM_BM) * p.tiles_n;
-    hipLaunchKernelGGL(dense_gemm_kernel, dim3((unsigned)tiles), dim3(512), DGM_LDS, stream, p);
+    int64_t nvb = ((int64_t)p.tiles_m * p.tiles_n + 7) / 8 * 8;
+    if (p.gn) {   // whole super-blocks, a multiple of 8 of them (one run per XCD)
+        const int64_t blocks = (int64_t)((p.tiles_m + DGM_GM - 1) / DGM_GM) * p.blocks_n;
+        nvb = (blocks + 7) / 8 * 8 * DGM_GM * p.gn;
+    }
+    p.nvb = (int)nvb;
+    int grid = 256;   // one persistent workgroup per CU; fewer when there are fewer tiles (always a multiple of 8)
+    if (const char* e = std::getenv("VTD_DGM_GRID")) grid = std::max(8, std::atoi(e) / 8 * 8);
+    if (nvb < grid) grid = (int)nvb;
+    if (flags & EPI_GELU) hipLaunchKernelGGL(dense_gemm_kernel<true>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+    else hipLaunchKernelGGL(dense_gemm_kernel<false>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
     return -(int)hipGetLastError();
 }

@@ -74,9 +74,11 @@ template <int MF, int NF>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
     __shared__ __attribute__((aligned(16))) float red[4 * (MF * NF < 8 ? MF * NF : 8) * 256];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    // The live row count is only needed to mask the stores: it is fetched here and consumed after the K loop, so its round trip is
+    // not at the head of every launch's dependent chain.  (Row tiles past the live rows -- at most the two steps' worth the host's
+    // bound lags behind -- read stale rows of valid buffers and write nothing.)
     const int rows = min(*p.n_rows, p.M);
     const int m0 = blockIdx.y * (16 * MF), n0 = blockIdx.x * (16 * NF);
-    if (m0 >= rows) return;   // uniform over the workgroup, before any barrier
     // the workgroup's K range in 32-deep sub-steps, dealt to the four waves as evenly as they divide (K = 192: 1 + 2 + 1 + 2)
     const int kper = p.K / p.ksplit, nsub = kper >> 5;     // host guarantees kper % 32 == 0
     const int sub0 = (nsub * w) >> 2, klen = (((nsub * (w + 1)) >> 2) - sub0) << 5;
@@ -89,7 +91,9 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = (MF + NF) <= 6 ? 4 : 2;   // 32-deep sub-steps whose loads are issued together (<= 24 x 16 bytes per lane in flight)
+    // 32-deep sub-steps whose loads are issued together (<= 24 x 16 bytes per lane in flight): a 16-row tile walks K = 1024 / 4 waves in ONE
+    // round trip, a 64-row tile in two
+    constexpr int U = 24 / (MF + NF) >= 8 ? 8 : 24 / (MF + NF) >= 6 ? 6 : 24 / (MF + NF) >= 4 ? 4 : 2;
     for (int k = 0; k < klen; k += 32 * U) {
         half8 a[U][MF], b[U][NF];
 #pragma unroll
@@ -150,8 +154,16 @@ struct DecLnParams {
 template <int MAXV4>
 __global__ __launch_bounds__(256) void dec_ln_kernel(DecLnParams p) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= min(*p.n_rows, p.M)) return;
-    floatx4 v[MAXV4];
+    if (row >= p.M) return;
+    const bool live = row < *p.n_rows;   // consumed at the stores only (see dec_gemm): not at the head of the dependent chain
+    floatx4 v[MAXV4], gam[MAXV4], bet[MAXV4];
+    // gamma / beta are fetched with the data, not after the two reductions (one memory round trip less in every launch of the chain)
+#pragma unroll
+    for (int i = 0; i < MAXV4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        gam[i] = bet[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (c < p.D) { gam[i] = *(const floatx4*)(p.gamma + c); bet[i] = *(const floatx4*)(p.beta + c); }
+    }
     float sum = 0.f;
     const float* erow = nullptr;
     if (p.embed) {
@@ -191,9 +203,11 @@ __global__ __launch_bounds__(256) void dec_ln_kernel(DecLnParams p) {
     for (int i = 0; i < MAXV4; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < p.D) {
-            const floatx4 n = (v[i] - mean) * rstd * *(const floatx4*)(p.gamma + c) + *(const floatx4*)(p.beta + c);
-            *(floatx4*)(p.x + (int64_t)row * p.D + c) = n;
-            *(half4*)(p.x16 + (int64_t)row * p.D + c) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
+            const floatx4 n = (v[i] - mean) * rstd * gam[i] + bet[i];
+            if (live) {
+                *(floatx4*)(p.x + (int64_t)row * p.D + c) = n;
+                *(half4*)(p.x16 + (int64_t)row * p.D + c) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
+            }
         }
     }
 }
@@ -215,20 +229,21 @@ struct DecAttnParams {
     int M;
 };
 
-// Workgroup = four waves per (row, head).  The first version gave a (row, head) to ONE wave that walked its keys eight at a time:
+// Workgroup = NW waves per (row, head) (4 for self-, 16 for cross-attention).  The first version gave a (row, head) to ONE wave that walked its keys eight at a time:
 // 73 dependent load -> use rounds per pass for the 577 encoder tokens, i.e. ~100 us per launch however few rows were live (measured:
-// 110 us at 64 live rows, 0.17 of the HBM rate).  Now the 256 threads cover 32 keys per round (eight lanes per 128-byte row), three
-// rounds are in flight per thread, the score pass and the value pass are each 6 dependent rounds for 577 tokens, and the partial
-// sums meet through LDS in a fixed order (bitwise repeatable).
-template <bool SELF>
-__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
+// 110 us at 64 live rows, 0.17 of the HBM rate).  Now the workgroup covers 8 NW keys per round (eight lanes per 128-byte row), three
+// rounds are in flight per thread -- the score pass and the value pass are each two dependent batches of loads for 577 tokens at
+// NW = 16 -- and the partial sums meet through LDS in a fixed order (bitwise repeatable).
+template <bool SELF, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_attn_kernel(DecAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* pr = (float*)smem;              // [L rounded up to 32] scores, then probabilities
-    float* red = pr + ((p.L + 31) & ~31);  // [4 waves][64] partial outputs; [0..7] block reductions
+    constexpr int KR = 8 * NW;             // keys per round (eight lanes per 128-byte row)
+    float* pr = (float*)smem;              // [L rounded up to KR] scores, then probabilities
+    float* red = pr + ((p.L + KR - 1) / KR) * KR;  // [NW waves][64] partial outputs; [0 .. 2 NW) block reductions
     const int j = blockIdx.y, head = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (j >= min(*p.n_rows, p.M)) return;
     const int crop = p.active[j];
-    const int sub = tid >> 3, seg = tid & 7;   // key within a round of 32, 16-byte segment of the row
+    const int sub = tid >> 3, seg = tid & 7;   // key within a round, 16-byte segment of the row
     const half_t* qrow = p.q + (int64_t)j * p.ldq + head * 64 + seg * 8;
     const half8 qv = *(const half8*)qrow;
     float qf[8];
@@ -249,17 +264,17 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     constexpr int U = 3;   // rounds in flight per thread
     // ---- scores
     float mx = -INFINITY;
-    for (int k0 = 0; k0 < L; k0 += 32 * U) {
+    for (int k0 = 0; k0 < L; k0 += KR * U) {
         half8 kv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = k0 + 32 * u + sub;
+            const int key = k0 + KR * u + sub;
             kv[u] = knew;
             if (key < L && !(SELF && key == L - 1)) kv[u] = *(const half8*)(kb + (int64_t)key * D);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = k0 + 32 * u + sub;
+            const int key = k0 + KR * u + sub;
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[u][e];
@@ -276,32 +291,36 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) red[w] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    // ---- softmax numerators and their sum (fixed order: thread strides, wave shuffles, waves 0..3)
+    mx = red[0];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) mx = fmaxf(mx, red[q]);
+    // ---- softmax numerators and their sum (fixed order: thread strides, wave shuffles, waves 0 .. NW-1)
     float sum = 0.f;
-    for (int key = tid; key < L; key += 256) {
+    for (int key = tid; key < L; key += 64 * NW) {
         const float e = expf(pr[key] - mx);
         pr[key] = e;
         sum += e;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) red[4 + w] = sum;
+    if (lane == 0) red[NW + w] = sum;
     __syncthreads();
-    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    sum = red[NW];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) sum += red[NW + q];
     // ---- weighted values
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < L; k0 += 32 * U) {
+    for (int k0 = 0; k0 < L; k0 += KR * U) {
         half8 vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = k0 + 32 * u + sub;
+            const int key = k0 + KR * u + sub;
             vv[u] = vnew;
             if (key < L && !(SELF && key == L - 1)) vv[u] = *(const half8*)(vb + (int64_t)key * D);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = k0 + 32 * u + sub;
+            const int key = k0 + KR * u + sub;
             if (key < L) {
                 const float pk = pr[key];
 #pragma unroll
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
         acc[e] += __shfl_xor(acc[e], 16);
         acc[e] += __shfl_xor(acc[e], 32);
     }
-    __syncthreads();   // red[0..7] have been read by everyone
+    __syncthreads();   // the block reductions in red[] have been read by everyone
     if (lane < 8) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[w * 64 + lane * 8 + e] = acc[e];
@@ -326,7 +345,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = tid * 8 + e;
-            hv[e] = (half_t)(((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) / sum);
+            float o = red[c];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) o += red[q * 64 + c];   // waves in order
+            hv[e] = (half_t)(o / sum);
         }
         *(half8*)(p.out + (int64_t)j * D + head * 64 + tid * 8) = hv;
     }
@@ -449,6 +471,13 @@ int vtd_launch_dec_gemm(const half_t* A, int lda, const half_t* W, const float* 
     if (wide) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile
         const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
         hipLaunchKernelGGL((dec_gemm_kernel<4, 4>), grid, dim3(256), 0, s, p);
+    } else if (M <= 16) {   // the tail of a decode (a handful of live rows): 16-row tiles, all of a wave's K range in one batch of loads.
+        // Tile height never changes a result: every output's K order (wave quarters, sub-steps in order) is the same in all variants.
+        const dim3 grid((N + 31) / 32, 1, ksplit);
+        hipLaunchKernelGGL((dec_gemm_kernel<1, 2>), grid, dim3(256), 0, s, p);
+    } else if (M <= 32) {
+        const dim3 grid((N + 31) / 32, 1, ksplit);
+        hipLaunchKernelGGL((dec_gemm_kernel<2, 2>), grid, dim3(256), 0, s, p);
     } else {
         const dim3 grid((N + 31) / 32, (M + 63) / 64, ksplit);
         hipLaunchKernelGGL((dec_gemm_kernel<4, 2>), grid, dim3(256), 0, s, p);
@@ -471,9 +500,15 @@ int vtd_launch_dec_attn(int self, const half_t* q, int ldq, half_t* kc, half_t* 
                         const int32_t* active, const int* n_rows_dev, int M, int heads, hipStream_t s) {
     if (L <= 0 || L > 16384 || heads * 64 != D || M <= 0) return -2504;
     DecAttnParams p{q, ldq, kc, vc, crop_stride, L, D, out, active, n_rows_dev, M};
-    const size_t lds = (size_t)(((L + 31) & ~31) + 256) * 4;
-    if (self) hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(heads, M), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(heads, M), dim3(256), lds, s, p);
+    // self-attention (<= max_length keys): 4 waves per (row, head); cross-attention (hundreds of encoder tokens): 16 waves, so that a
+    // (row, head)'s two passes are two dependent batches of loads each -- the launch's latency when only a few rows are left
+    if (self) {
+        const size_t lds = (size_t)((L + 31) / 32 * 32 + 4 * 64) * 4;
+        hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(heads, M), dim3(256), lds, s, p);
+    } else {
+        const size_t lds = (size_t)((L + 127) / 128 * 128 + 16 * 64) * 4;
+        hipLaunchKernelGGL((dec_attn_kernel<false, 16>), dim3(heads, M), dim3(1024), lds, s, p);
+    }
     return -(int)hipGetLastError();
 }
 
