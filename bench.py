@@ -195,6 +195,7 @@ def main():
         os.environ.setdefault("VTD_TROCR_SEEDED", "0")   # explicit opt-in: the architecture on synthetic weights (nothing is fetchable)
     pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64
+    pipe.detector.model._max_batch = B        # the engine is built at first use: size it for this batch (VTD_MAX_BATCH is read at import)
     pipe.detector.model.load_state_dict(sd)
     # VTD_BENCH_CRNN=default: torch-default-init recogniser weights (round-1 bench; every crop decodes to two characters)
     rec_sd = (mynets.seeded_state_dict(lambda: mynets.CRNN(97), seed=11) if os.environ.get("VTD_BENCH_CRNN") == "default"
@@ -390,7 +391,7 @@ def main():
             achieved = bytes_total / (ms * 1e-3) / 1e9
             traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")
             detector_roofline = roofline
-            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 16> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
+            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
                         "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
@@ -497,7 +498,7 @@ def read_sclk_mhz():
 # launch-slot description (vtd_api.cpp: vtd_detector_get_profile) -> device kernel symbol of exactly that variant
 KERNEL_SYMBOLS = (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
                   ("head_entry_halo256", "head_entry_halo256_kernel<false>("), ("head_entry_halo ", "head_entry_halo_kernel<"),
-                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 16>("))
+                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 4>("))
 
 
 def lookup_traffic(launch_name, profiles_dir=None):

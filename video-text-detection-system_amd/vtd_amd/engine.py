@@ -549,13 +549,14 @@ class TrOCREngine(_Tunable):
         return torch.cat(outs)
 
     # ---- pipelined use: the encoder pass of batch i+1 (MFMA-bound) overlaps the decode of batch i (latency- / HBM-bound) -------------
-    def decode_stream(self):
-        """The stream the pipelined decodes run on: the caller's by default.  VTD_TROCR_DEC_STREAM=1 gives them a high-priority stream of
-        their own so that the encoder pass of ticket i+1 runs beside the decode of ticket i.  Measured (kernel trace):
-        side by side the decoder's ~6.7 k small dependent launches wait for CU slots behind the encoder's wide ones (10 -> 50 us each)
-        and the encoder pass doubles -- 225 ms for the pair against 167 ms back to back -- so back to back is the default."""
+    def decode_stream(self, chunk=None):
+        """The stream a ticket's decode runs on: the one its encoder pass was enqueued on (back to back).  VTD_TROCR_DEC_STREAM=1 gives
+        the decodes a high-priority stream of their own so that the encoder pass of ticket i+1 runs beside the decode of ticket i.
+        Measured (kernel traces): side by side the decoder's ~6.7 k small dependent launches wait for CU slots
+        behind the encoder's wide ones (10 -> 50 us each) and the encoder pass doubles -- 225 ms for the pair against 165 ms back to
+        back -- so back to back is the default."""
         if os.environ.get("VTD_TROCR_DEC_STREAM", "0") != "1":
-            return torch.cuda.current_stream()
+            return chunk["stream"] if chunk is not None else torch.cuda.current_stream()
         if self._dec_stream is None:
             self._dec_stream = torch.cuda.Stream(priority=-1)
         return self._dec_stream
@@ -571,7 +572,7 @@ class TrOCREngine(_Tunable):
                 self._next_slot = (slot + 1) % self.slots
                 if self._slot_ticket[slot] is not None:
                     self._decode(self._slot_ticket[slot])
-                chunk = {"slot": slot, "n": 0, "ids": None, "frames": frames}
+                chunk = {"slot": slot, "n": 0, "ids": None, "frames": frames, "stream": torch.cuda.current_stream()}
                 chunk["n"] = self.encode_crops(frames, boxes[i:i + self.max_crops], slot)
                 chunk["encoded"] = torch.cuda.Event()
                 chunk["encoded"].record()
@@ -583,7 +584,7 @@ class TrOCREngine(_Tunable):
         """Greedy decode of one encoded chunk on the decode stream + asynchronous copy of the ids to pinned memory (lock held)."""
         if chunk["ids"] is not None:
             return
-        with torch.cuda.stream(self.decode_stream()):
+        with torch.cuda.stream(self.decode_stream(chunk)):
             ids, _ = self._enqueue_generate(chunk["n"], chunk["slot"])
             host = PINNED.take(tuple(ids.shape))
             host.copy_(ids, non_blocking=True)
@@ -612,7 +613,8 @@ class TrOCREngine(_Tunable):
     def profile(self):
         """(total ms, launches, summed row counts) of the bracketed cross-attention launches since the last call."""
         ms, calls, rows = C.c_double(), C.c_int64(), C.c_int64()
-        stream = self._dec_stream if self._dec_stream is not None else torch.cuda.current_stream()
+        stream = self._dec_stream if self._dec_stream is not None else torch.cuda.current_stream()   # get_profile waits for it
+        torch.cuda.synchronize()
         _native.check(self.lib.vtd_trocr_get_profile(self.handle, C.byref(ms), C.byref(calls), C.byref(rows), C.c_void_p(stream.cuda_stream)),
                       "vtd_trocr_get_profile")
         return ms.value, calls.value, rows.value
