@@ -523,8 +523,16 @@ def lookup_traffic(launch_name, profiles_dir=None):
         return None, None, (f"roofline.traffic: {os.path.basename(pmc_path)} has no entry for kernel symbol {symbol!r}: the PMC passes are "
                             "stale for the kernel that now dominates -- re-run tools/gpu_evidence.sh and commit the summary")
     v = max(hits, key=lambda h: h["launches"])
+    extra = {}
+    if "dec_attn" in symbol:
+        # the decoder's launches shrink with the live rows: cite the LARGEST grid (all rows live) and say how many rows that was, so the
+        # figure can be set against the algorithmic bytes of the same launch (rows x 577 x 1024 x 2 B x 2)
+        key = max((k for k, h in pmc.items() if symbol in k and h.get("launches", 0) >= 3), key=lambda k: int(k.rsplit("grid=", 1)[1]))
+        v = pmc[key]
+        rows_ = int(key.rsplit("grid=", 1)[1]) // (16 * 256)
+        extra = {"live_rows_of_that_launch": rows_, "algorithmic_bytes_of_that_launch": rows_ * 577 * 1024 * 2 * 2}
     rd, wr = v["hbm_read_MB_corrected_x2"], v["hbm_write_MB"]
-    detail = {"hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2), "kernel_symbol": symbol,
+    detail = {**extra, "hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2), "kernel_symbol": symbol,
               "source": "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median over launches, "
                         "FETCH_SIZE x2 per the gfx950 note)"}
     return int((rd + wr) * 1e6), detail, None
@@ -568,10 +576,11 @@ def cpu_baselines(args, frames, sd, rec_sd):
 
     opipe.detect(frames[0], sd, args.backbone, 0.5)  # warm-up (oneDNN primitive creation)
     # (i) reference-shaped: rounds of 4 frames, detect on a 4-thread pool, crops one by one (pipeliine.py:96-133)
+    # (the Transformer recogniser costs seconds per crop on the CPU: its sample is one frame)
     done, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(max_workers=4) as pool:
         while done < B and time.perf_counter() - t0 < args.cpu_seconds:
-            chunk = frames[done:done + 4]
+            chunk = frames[done:done + (1 if trocr and full else 4)]
             dets = list(pool.map(lambda f: opipe.detect(f, sd, args.backbone, 0.5), chunk))
             if full:
                 for fr, ds in zip(chunk, dets):
@@ -582,7 +591,7 @@ def cpu_baselines(args, frames, sd, rec_sd):
     shaped = {"value": round(done / dt_ref, 3), "unit": "frames/s", "cores": ncores, "threads": "4 Python threads x torch intra-op pool",
               "sample": f"{done} of the step's {B} frames"}
     # (ii) best-case batched: one forward over the sample, every crop in one recogniser batch
-    nb = B if args.cpu_seconds >= 10 and not trocr else max(1, min(B, 4 if trocr else 8))
+    nb = B if args.cpu_seconds >= 10 and not trocr else max(1, min(B, 2 if trocr else 8))
     sample = frames[:nb]
     t0 = time.perf_counter()
     x = torch.cat([opipe.preprocess(f) for f in sample])
