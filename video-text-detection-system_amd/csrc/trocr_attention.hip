@@ -1,0 +1,212 @@
+// Encoder self-attention of the Transformer recogniser (ViT: 577 tokens, heads of 64; reference text_recognizer.py:55-60 ->
+// transformers ViTSelfAttention: softmax(Q K^T / 8) V), flash style on v_mfma_f32_16x16x32_f16.
+//
+//   S^T = K Q^T    so a lane owns one query column: the online softmax runs on the accumulator registers (two shfl_xor per reduction)
+//                  and the probabilities feed the second MFMA directly as its K-permuted operand -- no LDS round trip for P;
+//   O^T = V^T P^T  needs V with the KEYS contiguous.  The first version transposed V while staging it (eight 2-byte LDS writes per
+//                  thread and key block, behind two barriers per 32 keys, 64 queries per workgroup): 1.3 ms per layer at 272 crops =
+//                  0.21 PFLOP/s.  Now a small pre-pass (trocr_vt_kernel) writes V^T per (crop, head) once -- [64][Tpad] fp16, zero padded --
+//                  and the attention kernel stages K [64 keys][64] and V^T [64][64 keys] tiles with plain 16-byte accesses;
+//   tile           128 queries per workgroup (4 waves x 2 query fragments) against key blocks of 64: the K / V^T tile traffic and the
+//                  barriers per query are a quarter of the first version's; the next block's tiles are fetched into registers while the
+//                  current block multiplies (one barrier pair per 64 keys).
+#include <cmath>
+#include "vtd_common.h"
+
+namespace {
+
+constexpr int AT_KB = 64;      // keys per block
+constexpr int AT_PAD = 72;     // halfs per LDS row (64 + 8: conflict-free 16-byte fragment reads)
+
+// V^T[b][head][d][t] = qkv[b][t][2 C + head * 64 + d], t < T (zeros up to Tpad).  Workgroup = 64 tokens of one (b, head).
+__global__ __launch_bounds__(256) void trocr_vt_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ vt, int T, int Tpad, int C) {
+    __shared__ half_t tile[64 * 66];
+    const int b = blockIdx.z, head = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int64_t ld = 3 * (int64_t)C;
+    {
+        const int row = tid >> 2, seg = (tid & 3) * 16;   // token row, 16 halfs of its 64
+        const int t = t0 + row;
+        half8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = a;
+        if (t < T) {
+            const half_t* src = qkv + ((int64_t)b * T + t) * ld + 2 * C + head * 64 + seg;
+            a = *(const half8*)src;
+            c = *(const half8*)(src + 8);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            tile[(seg + e) * 66 + row] = a[e];
+            tile[(seg + 8 + e) * 66 + row] = c[e];
+        }
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, seg = (tid & 3) * 16;     // output row d, 16 tokens of the 64
+        half_t* dst = vt + (((int64_t)b * gridDim.y + head) * 64 + d) * Tpad + t0 + seg;
+        half8 a, c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = tile[d * 66 + seg + e];
+            c[e] = tile[d * 66 + seg + 8 + e];
+        }
+        if (t0 + seg < Tpad) *(half8*)dst = a;
+        if (t0 + seg + 8 < Tpad) *(half8*)(dst + 8) = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ vt, half_t* __restrict__ out,
+                                                              int T, int Tpad, int C, float scale) {
+    __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PAD];   // K tile, key-major
+    __shared__ __attribute__((aligned(16))) half_t vs[2][64 * AT_PAD];      // V^T tile, d-major
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int64_t ld = 3 * (int64_t)C;
+    const half_t* base = qkv + (int64_t)b * T * ld + head * 64;
+    const half_t* vbase = vt + ((int64_t)b * gridDim.y + head) * 64 * Tpad;
+    // Q fragments (second MFMA operand: column = query fr, K chunk fq), pre-scaled; wave w owns queries q0 + 32 w + 16 g + fr
+    half8 qf[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int q = q0 + w * 32 + g * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < T) t = *(const half8*)(base + (int64_t)q * ld + kk * 32 + fq * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (half_t)((float)t[e] * scale);
+            qf[g][kk] = t;
+        }
+    }
+    floatx4 acc_o[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc_o[g][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    // staging: thread -> (row 0..63, 32-byte half of... ) two 16-byte pieces per tile and thread
+    const int srow = tid >> 2, scol = (tid & 3) * 16;   // row of the tile, first of 16 halfs
+    auto fetch = [&](int k0, half8* kreg, half8* vreg) {
+        int key = k0 + srow;
+        key = key < T ? key : T - 1;   // rows past the end: any valid row (their scores are masked)
+        const half_t* ksrc = base + (int64_t)key * ld + C + scol;
+        kreg[0] = *(const half8*)ksrc;
+        kreg[1] = *(const half8*)(ksrc + 8);
+        const half_t* vsrc = vbase + (int64_t)srow * Tpad + k0 + scol;   // d = srow, keys k0 + scol .. (zero padded to Tpad)
+        vreg[0] = *(const half8*)vsrc;
+        vreg[1] = *(const half8*)(vsrc + 8);
+    };
+    auto stage = [&](int buf, const half8* kreg, const half8* vreg) {
+        *(half8*)(&ks[buf][srow * AT_PAD + scol]) = kreg[0];
+        *(half8*)(&ks[buf][srow * AT_PAD + scol + 8]) = kreg[1];
+        *(half8*)(&vs[buf][srow * AT_PAD + scol]) = vreg[0];
+        *(half8*)(&vs[buf][srow * AT_PAD + scol + 8]) = vreg[1];
+    };
+    half8 kreg[2], vreg[2];
+    fetch(0, kreg, vreg);
+    stage(0, kreg, vreg);
+    __syncthreads();
+    const int nblk = (T + AT_KB - 1) / AT_KB;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int k0 = blk * AT_KB, buf = blk & 1;
+        if (blk + 1 < nblk) fetch(k0 + AT_KB, kreg, vreg);   // in flight under this block's maths
+        // S^T[key][q] for the block: 4 key fragments x 2 query fragments, K dim 64 = 2 x 32
+        floatx4 s[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) s[g][kf] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const half8 ka = *(const half8*)(&ks[buf][(kf * 16 + fr) * AT_PAD + kk * 32 + fq * 8]);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) s[g][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[g][kk], s[g][kf], 0, 0, 0);
+            }
+        // online softmax: lane holds keys k0 + 16 kf + 4 fq + e of query fr (per query fragment g).  The softmax pass is what bounds
+        // this kernel (32 scores per lane and block against 32 MFMAs per wave): exponentials run as ONE v_exp_f32 each on
+        // fma(s, log2 e, -m log2 e) instead of libdevice's expf (~10 instructions), and only the last key block pays for the
+        // out-of-range mask.
+        constexpr float LOG2E = 1.4426950408889634f;
+        const bool partial = k0 + AT_KB > T;
+        half8 pf[2][2];   // [g][key half]: probabilities in the key order (kf = 2 h: 4 fq + e, kf = 2 h + 1: 16 + 4 fq + e) of the PV operand
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (partial) {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + kf * 16 + fq * 4 + e >= T) s[g][kf][e] = -INFINITY;
+            }
+            float bm = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bm = fmaxf(bm, s[g][kf][e]);
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float m_new = fmaxf(m_run[g], bm);          // finite from the first block on (every block holds a real key)
+            const float mneg = -m_new * LOG2E;
+            const float corr = __builtin_amdgcn_exp2f((m_run[g] - m_new) * LOG2E);   // first block: exp2(-inf) = 0
+            float ps = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[g][kf][e], LOG2E, mneg));
+                    ps += pv;
+                    pf[g][kf >> 1][(kf & 1) * 4 + e] = (half_t)pv;
+                }
+            l_run[g] = l_run[g] * corr + ps;
+            m_run[g] = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_o[g][i] *= corr;
+        }
+        // O^T += V^T P^T: d fragments i, key halves h (32 keys each, in the permuted order of pf)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const half4 va = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PAD + h * 32 + fq * 4]);
+                const half4 vb = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PAD + h * 32 + 16 + fq * 4]);
+                const half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc_o[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[g][h], acc_o[g][i], 0, 0, 0);
+            }
+        if (blk + 1 < nblk) {
+            stage(buf ^ 1, kreg, vreg);   // the other buffer: last read in block blk - 1, behind the barrier below of that iteration
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float l = l_run[g];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int q = q0 + w * 32 + g * 16 + fr;
+        if (q < T) {
+            const float inv = 1.0f / l;
+            half_t* o = out + ((int64_t)b * T + q) * C + head * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc_o[g][i][e] * inv);
+                *(half4*)(o + i * 16 + fq * 4) = hv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// keys padded to a multiple of the key block (+ one block so that the tile fetch of the last block stays inside the row)
+int vtd_trocr_attention_tpad(int T) { return (T + AT_KB - 1) / AT_KB * AT_KB; }
+
+int vtd_launch_trocr_attention(const half_t* qkv, half_t* vt, half_t* out, int n, int T, int C, int heads, hipStream_t s) {
+    if (heads * 64 != C || n <= 0 || T <= 0 || !vt) return -2404;
+    const int Tpad = vtd_trocr_attention_tpad(T);
+    hipLaunchKernelGGL(trocr_vt_kernel, dim3(Tpad / 64, heads, n), dim3(256), 0, s, qkv, vt, T, Tpad, C);
+    hipLaunchKernelGGL(trocr_attention_kernel, dim3((T + 127) / 128, heads, n), dim3(256), 0, s, qkv, vt, out, T, Tpad, C, 0.125f);
+    return -(int)hipGetLastError();
+}
