@@ -299,6 +299,11 @@ def main():
     for _ in range(ROTATE if args.mixed else 1):
         step()
     drain()
+    # From here on the loop runs as VideoTextPipeline.process_video runs it: with the long-lived heap out of the cyclic collector's
+    # sight (vtd_amd.pipeline.quiet_gc; VTD_QUIET_GC=0 to see what the collector costs: 12 % of the sustained rate)
+    from vtd_amd.pipeline import quiet_gc
+    gc_guard = quiet_gc()
+    gc_guard.__enter__()
     for _ in range(args.warmup):
         step()
     drain()
@@ -321,12 +326,18 @@ def main():
     if teng is not None and not args.no_profile:
         teng.profile()                 # drop what the warm-up left
         teng.set_profiling(1)          # HIP events around the decoder's cross-attention launch (layer 0 of every step), on its stream
+    stamps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         blocks = step()
+        stamps.append(time.perf_counter())
     drain()  # K batches submitted -> K batches retired (result dicts built) inside the timed region
+    stamps.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("VTD_BENCH_STAMPS") == "1" and rank == 0:
+        print("per-step host times (ms): " + " ".join(f"{1e3 * (b - a):.2f}" for a, b in zip([t0] + stamps, stamps)) +
+              f" | barrier {1e3 * (t0 + elapsed - stamps[-1]):.2f}", file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -448,6 +459,7 @@ def main():
     if rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         cpu_baseline = cpu_baselines(args, frames, sd, rec_sd)
 
+    gc_guard.__exit__(None, None, None)
     if rank == 0:
         total_frames = world * B * args.steps
         out = {
