@@ -162,9 +162,9 @@ def test_quiet_gc_hands_the_heap_back_and_respects_a_host_freeze(monkeypatch):
     monkeypatch.delenv("VTD_QUIET_GC")
     gc.freeze()                          # the host's own freeze (e.g. a pre-fork server)
     try:
-        before = gc.get_freeze_count()
         with quiet_gc():
-            assert gc.get_freeze_count() >= before
-        assert gc.get_freeze_count() >= before > 0
+            assert gc.get_freeze_count() > 0
+        assert gc.get_freeze_count() > 0     # still frozen: the host's permanent generation was not handed back (the count itself
+                                             # may shrink: frozen objects are still freed by reference counting)
     finally:
         gc.unfreeze()
