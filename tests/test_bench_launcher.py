@@ -60,3 +60,15 @@ def test_roofline_traffic_lookup_covers_the_shipped_dominant_kernel_and_fails_lo
     assert t is None and "no kernel symbol known" in err
     t, d, err = bench.lookup_traffic(name, profiles_dir=str(tmp_path / "empty"))
     assert t is None and "no profiles/" in err
+
+
+def test_roofline_traffic_lookup_for_the_transformer_line():
+    """The Transformer lines name the decoder's cross-attention; its launches shrink with the live rows, so the lookup cites the LARGEST
+    measured grid together with its row count -- and that figure must agree with the algorithmic bytes of the same launch (every key /
+    value byte of a live row is read exactly once per layer and step)."""
+    import bench
+    traffic, detail, err = bench.lookup_traffic("dec_cross_attn")
+    assert err is None and detail["kernel_symbol"].startswith("dec_attn_kernel<false")
+    rows = detail["live_rows_of_that_launch"]
+    assert rows >= 256
+    assert 0.95 <= traffic / detail["algorithmic_bytes_of_that_launch"] <= 1.10

@@ -54,14 +54,21 @@ __global__ __launch_bounds__(256) void trocr_vt_kernel(const half_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ vt, half_t* __restrict__ out,
-                                                              int T, int Tpad, int C, float scale) {
+                                                              int T, int Tpad, int C, float scale, int heads, int units, int qtiles) {
     __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PAD];   // K tile, key-major
     __shared__ __attribute__((aligned(16))) half_t vs[2][64 * AT_PAD];      // V^T tile, d-major
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+    // Workgroup -> (crop, head, query tile).  The query tiles of one (crop, head) read the same K and V^T rows (148 KB): they must run on
+    // ONE XCD to find them in its L2.  Consecutive workgroup ids go to different XCDs, so XCD x = id % 8 takes the units x, x + 8, ...
+    // and walks each unit's `qtiles` tiles back to back (PMC before: 3.0 GB read per launch at 287 crops, every tile fetching K / V^T
+    // from HBM; algorithmic 1.0 GB).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int unit = (idx / qtiles) * 8 + xcd, qt = idx - (idx / qtiles) * qtiles;
+    if (unit >= units) return;   // padding of the last group of eight units (uniform over the workgroup, before any barrier)
+    const int b = unit / heads, head = unit - b * heads, q0 = qt * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int64_t ld = 3 * (int64_t)C;
     const half_t* base = qkv + (int64_t)b * T * ld + head * 64;
-    const half_t* vbase = vt + ((int64_t)b * gridDim.y + head) * 64 * Tpad;
+    const half_t* vbase = vt + ((int64_t)b * heads + head) * 64 * Tpad;
     // Q fragments (second MFMA operand: column = query fr, K chunk fq), pre-scaled; wave w owns queries q0 + 32 w + 16 g + fr
     half8 qf[2][2];
 #pragma unroll
@@ -207,6 +214,8 @@ int vtd_launch_trocr_attention(const half_t* qkv, half_t* vt, half_t* out, int n
     if (heads * 64 != C || n <= 0 || T <= 0 || !vt) return -2404;
     const int Tpad = vtd_trocr_attention_tpad(T);
     hipLaunchKernelGGL(trocr_vt_kernel, dim3(Tpad / 64, heads, n), dim3(256), 0, s, qkv, vt, T, Tpad, C);
-    hipLaunchKernelGGL(trocr_attention_kernel, dim3((T + 127) / 128, heads, n), dim3(256), 0, s, qkv, vt, out, T, Tpad, C, 0.125f);
+    const int qtiles = (T + 127) / 128, units = heads * n;
+    const int64_t grid = (int64_t)((units + 7) / 8) * 8 * qtiles;
+    hipLaunchKernelGGL(trocr_attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, qkv, vt, out, T, Tpad, C, 0.125f, heads, units, qtiles);
     return -(int)hipGetLastError();
 }
