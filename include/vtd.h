@@ -191,6 +191,13 @@ int vtd_trocr_num_slots(const vtd_trocr* t);
 int vtd_trocr_encode_crops_slot(vtd_trocr* t, int slot, const uint8_t* frames_dev, int n_frames, int height, int width, const int32_t* boxes_host,
                                 int ncrops, vtd_stream stream);
 int vtd_trocr_encode_pixels_slot(vtd_trocr* t, int slot, const float* pixel_values_dev, int ncrops, vtd_stream stream);
+/* encode_crops in two halves, so that one encoder pass + decode can serve the crops of SEVERAL frame batches (their frame sizes may
+ * differ): stage_crops runs the processor (text_recognizer.py:49-52) for the boxes of one resident frame batch into rows
+ * [row_offset, row_offset + ncrops) of the slot, encode_staged runs the ViT encoder and the cross-attention keys / values over the first
+ * ncrops staged rows.  The decode's cost per step is mostly fixed, so merged recogniser batches are much cheaper per crop. */
+int vtd_trocr_stage_crops_slot(vtd_trocr* t, int slot, const uint8_t* frames_dev, int n_frames, int height, int width, const int32_t* boxes_host,
+                               int ncrops, int row_offset, vtd_stream stream);
+int vtd_trocr_encode_staged_slot(vtd_trocr* t, int slot, int ncrops, vtd_stream stream);
 int vtd_trocr_generate_slot(vtd_trocr* t, int slot, int ncrops, int max_length, const int32_t* forced_ids_dev, int forced_len, int32_t* ids_dev,
                             float* logits_dev, vtd_stream stream);
 int vtd_trocr_last_steps(const vtd_trocr* t);

@@ -224,29 +224,38 @@ def test_decode_is_bitwise_repeatable_and_slots_are_independent(base):
     assert np.array_equal(got_a.numpy(), ids_a.numpy()) and np.array_equal(got_b.numpy(), ids_b.numpy())
 
 
-def test_pipelined_tickets_equal_the_synchronous_calls(base):
-    """TrOCREngine.submit_crops / finish (encoder pass of ticket i+1 enqueued before ticket i is decoded, decode on its own stream):
-    three tickets in flight order, one of them larger than max_crops (two chunks: the second reuses a slot whose pass must be decoded
-    first) -- ids equal generate_crops on the same boxes."""
+def test_queued_tickets_share_one_pass_and_equal_the_synchronous_calls(base, monkeypatch):
+    """TrOCREngine.submit_crops only queues; finish() runs ONE encoder pass + ONE decode for everything queued (crops of several frame
+    batches, of different frame sizes too, staged into one slot).  Three tickets: two small ones that merge (one of them from 1080p
+    frames), one larger than max_crops (cut into two passes, the queue flushed to make room) -- every ticket's ids equal
+    generate_crops on its own boxes, and with VTD_TROCR_MERGE=0 (every ticket on its own) as well."""
     from vtd_amd.engine import DeviceFrames
     eng, sd = base
-    groups = [[synth.glyph_crop(980 + i) for i in range(4)], [synth.glyph_crop(990 + i) for i in range(eng.max_crops + 3)],
-              [synth.glyph_crop(1030 + i) for i in range(2)]]
+    groups = [[synth.glyph_crop(980 + i) for i in range(4)], [synth.glyph_crop(1030 + i) for i in range(5)],
+              [synth.glyph_crop(990 + i) for i in range(eng.max_crops + 3)]]
     batches = []
-    for crops in groups:
+    for gi, crops in enumerate(groups):
         frames, boxes = _crops_in_frames(crops[:8])
+        if gi == 1:   # a frame batch of another size in the same pass
+            big = np.zeros((frames.shape[0], 1080, 1920, 3), np.uint8)
+            big[:, :720, :1280] = frames
+            frames = big
         # more crops than frames fit: reuse the first frames' boxes cyclically (same content, same ids)
         boxes = [boxes[i % len(boxes)] for i in range(len(crops))]
         batches.append((DeviceFrames(frames), boxes))
     want = [eng.generate_crops(fr, bx).numpy() for fr, bx in batches]
-    t0 = eng.submit_crops(*batches[0])
-    t1 = eng.submit_crops(*batches[1])
-    got0 = eng.finish(t0).numpy()
-    t2 = eng.submit_crops(*batches[2])
-    got1 = eng.finish(t1).numpy()
-    got2 = eng.finish(t2).numpy()
-    for g, w in zip((got0, got1, got2), want):
-        assert np.array_equal(g, w)
+    for merge in ("1", "0"):
+        monkeypatch.setenv("VTD_TROCR_MERGE", merge)
+        t0 = eng.submit_crops(*batches[0])
+        t1 = eng.submit_crops(*batches[1])
+        assert (t0["parts"] is None and t1["parts"] is None) == (merge == "1")     # queued, nothing enqueued yet
+        got0 = eng.finish(t0).numpy()                                               # flushes t0 + t1 as one pass of 9 rows
+        assert t1["parts"] is not None
+        t2 = eng.submit_crops(*batches[2])
+        got1 = eng.finish(t1).numpy()
+        got2 = eng.finish(t2).numpy()
+        for g, w in zip((got0, got1, got2), want):
+            assert np.array_equal(g, w)
 
 
 def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golden_dir, monkeypatch):

@@ -81,6 +81,8 @@ SIGNATURES = {
     "vtd_trocr_num_slots": (C.c_int, [C.c_void_p]),
     "vtd_trocr_encode_crops_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vtd_trocr_encode_pixels_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtd_trocr_stage_crops_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vtd_trocr_encode_staged_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vtd_trocr_generate_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vtd_trocr_last_steps": (C.c_int, [C.c_void_p]),
     "vtd_trocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

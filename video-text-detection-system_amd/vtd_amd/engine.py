@@ -465,7 +465,7 @@ class TrOCREngine(_Tunable):
         self.logits_stride = int(self.lib.vtd_trocr_logits_stride(h))
         self.slots = int(self.lib.vtd_trocr_num_slots(h))
         self._next_slot = 0
-        self._slot_ticket = [None] * self.slots     # the ticket whose encoder output lives in the slot and is not decoded yet
+        self._queue = []          # tickets whose crops are not staged yet (submit_crops / finish)
         self._dec_stream = None
 
     def close(self):
@@ -548,64 +548,105 @@ class TrOCREngine(_Tunable):
                 outs.append(self.generate_current(n, **kw)[0])
         return torch.cat(outs)
 
-    # ---- pipelined use: the encoder pass of batch i+1 (MFMA-bound) overlaps the decode of batch i (latency- / HBM-bound) -------------
-    def decode_stream(self, chunk=None):
-        """The stream a ticket's decode runs on: the one its encoder pass was enqueued on (back to back).  VTD_TROCR_DEC_STREAM=1 gives
-        the decodes a high-priority stream of their own so that the encoder pass of ticket i+1 runs beside the decode of ticket i.
-        Measured (kernel traces): side by side the decoder's ~6.7 k small dependent launches wait for CU slots
-        behind the encoder's wide ones (10 -> 50 us each) and the encoder pass doubles -- 225 ms for the pair against 165 ms back to
-        back -- so back to back is the default."""
+    # ---- pipelined use: recogniser batches are decoupled from detector batches ---------------------------------------------------
+    # A decode step costs about the same whether 30 or 300 rows are live (~136 dependent launches), so crops are worth collecting:
+    # submit_crops only QUEUES a ticket; the GPU work starts when some ticket's result is asked for (finish) or the queue would
+    # overflow the workspace, and then every queued ticket is staged into ONE encoder pass and ONE decode.  In the three-deep video
+    # loop (submit ticket i, then finish ticket i-1) that merges tickets in pairs with no extra latency in batches.
+    def decode_stream(self, stream=None):
+        """The stream a merged pass's decode runs on: the one its encoder pass was enqueued on (back to back).  VTD_TROCR_DEC_STREAM=1
+        gives the decodes a high-priority stream of their own so that the next encoder pass runs beside them.  Measured (kernel
+        traces): side by side the decoder's ~6.7 k small dependent launches wait for CU slots behind the encoder's
+        wide ones (10 -> 50 us each) and the encoder pass doubles -- 225 ms for the pair against 165 ms back to back -- so back to
+        back is the default."""
         if os.environ.get("VTD_TROCR_DEC_STREAM", "0") != "1":
-            return chunk["stream"] if chunk is not None else torch.cuda.current_stream()
+            return stream if stream is not None else torch.cuda.current_stream()
         if self._dec_stream is None:
             self._dec_stream = torch.cuda.Stream(priority=-1)
         return self._dec_stream
 
     def submit_crops(self, frames, boxes):
-        """Enqueue the encoder pass (crop -> processor -> ViT -> cross-attention keys / values) for `boxes` on the caller's stream, in
-        chunks of max_crops, alternating between the handle's slots; nothing synchronises.  Returns a ticket for ``finish``.  A
-        chunk whose slot still holds an undecoded pass decodes that pass first (its ids stay with its ticket)."""
-        chunks = []
+        """Queue the crops `boxes` ([(frame, x1, y1, x2, y2), ...]) of a resident frame batch; returns a ticket for ``finish``.  Nothing
+        is enqueued on the GPU unless the queue has to be flushed to make room (VTD_TROCR_MERGE=0: every ticket runs on its own,
+        at once)."""
+        b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
+        ticket = {"boxes": b, "frames": frames, "stream": torch.cuda.current_stream(), "parts": None}
         with self.lock:
-            for i in range(0, len(boxes), self.max_crops):
-                slot = self._next_slot
-                self._next_slot = (slot + 1) % self.slots
-                if self._slot_ticket[slot] is not None:
-                    self._decode(self._slot_ticket[slot])
-                chunk = {"slot": slot, "n": 0, "ids": None, "frames": frames, "stream": torch.cuda.current_stream()}
-                chunk["n"] = self.encode_crops(frames, boxes[i:i + self.max_crops], slot)
-                chunk["encoded"] = torch.cuda.Event()
-                chunk["encoded"].record()
-                self._slot_ticket[slot] = chunk
-                chunks.append(chunk)
-        return chunks
+            if getattr(self, "_queue", None) is None:
+                self._queue = []
+            if sum(len(t["boxes"]) for t in self._queue) + len(b) > self.max_crops:
+                self._flush()
+            self._queue.append(ticket)
+            if os.environ.get("VTD_TROCR_MERGE", "1") == "0":
+                self._flush()
+        return ticket
 
-    def _decode(self, chunk):
-        """Greedy decode of one encoded chunk on the decode stream + asynchronous copy of the ids to pinned memory (lock held)."""
-        if chunk["ids"] is not None:
+    def _flush(self):
+        """One encoder pass + one decode for everything queued (lock held).  Tickets larger than the workspace are cut into passes of
+        max_crops rows; every ticket ends up with a list of (host ids, event, first row, rows)."""
+        queue, self._queue = getattr(self, "_queue", None) or [], []
+        if not queue:
             return
-        with torch.cuda.stream(self.decode_stream(chunk)):
-            ids, _ = self._enqueue_generate(chunk["n"], chunk["slot"])
-            host = PINNED.take(tuple(ids.shape))
-            host.copy_(ids, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        chunk.update(ids=ids, host=host, event=ev)
-        if self._slot_ticket[chunk["slot"]] is chunk:
-            self._slot_ticket[chunk["slot"]] = None
+        rows = [(t, i) for t in queue for i in range(len(t["boxes"]))]
+        for t in queue:
+            t["parts"] = []
+        stream = queue[-1]["stream"]
+        for start in range(0, len(rows), self.max_crops):
+            chunk = rows[start:start + self.max_crops]
+            slot = self._next_slot
+            self._next_slot = (slot + 1) % self.slots
+            with torch.cuda.stream(stream):
+                # runs of consecutive rows of one ticket are staged with one processor launch each
+                off, k = 0, 0
+                while k < len(chunk):
+                    t, i0 = chunk[k]
+                    k2 = k
+                    while k2 < len(chunk) and chunk[k2][0] is t:
+                        k2 += 1
+                    n = k2 - k
+                    fr = t["frames"]
+                    fr.wait_ready()
+                    bb = np.ascontiguousarray(t["boxes"][i0:i0 + n])
+                    _native.check(self.lib.vtd_trocr_stage_crops_slot(self.handle, slot, C.c_void_p(fr.tensor.data_ptr()), fr.n, fr.height, fr.width,
+                                                                      bb.ctypes.data, n, off, _stream_ptr()), "vtd_trocr_stage_crops")
+                    t.setdefault("spans", []).append((start, off, i0, n))
+                    off += n
+                    k = k2
+                _native.check(self.lib.vtd_trocr_encode_staged_slot(self.handle, slot, off, _stream_ptr()), "vtd_trocr_encode_staged")
+            with torch.cuda.stream(self.decode_stream(stream)):
+                ids, _ = self._enqueue_generate(off, slot)
+                host = PINNED.take(tuple(ids.shape))
+                host.copy_(ids, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            part = {"host": host, "event": ev, "ids": ids, "users": 0}
+            for t in queue:
+                mine = [(o, i0, n) for (st, o, i0, n) in t.get("spans", []) if st == start]
+                if mine:
+                    t["parts"].append((part, mine))
+                    part["users"] += 1
+        for t in queue:
+            t.pop("spans", None)    # (a ticket keeps its frames until it is finished: the processor launches read them asynchronously)
 
-    def finish(self, chunks):
-        """ids [n, max_length] int32 (cpu) of a ticket: decodes what is still only encoded, then waits for the copies."""
-        outs = []
+    def finish(self, ticket):
+        """ids [n, max_length] int32 (cpu) of a ticket, rows in the order of its boxes.  Flushes the queue when the ticket is still in
+        it (every ticket queued by then shares the pass)."""
         with self.lock:
-            for chunk in chunks:
-                self._decode(chunk)
-        for chunk in chunks:
-            chunk["event"].synchronize()
-            outs.append(chunk["host"].clone())
-            PINNED.release(chunk["host"])
-            chunk["frames"] = None
-        return torch.cat(outs) if outs else torch.empty((0, self.spec.max_length), dtype=torch.int32)
+            if ticket["parts"] is None:
+                self._flush()
+        n = len(ticket["boxes"])
+        out = torch.empty((n, self.spec.max_length), dtype=torch.int32)
+        for part, spans in ticket["parts"]:
+            part["event"].synchronize()
+            for off, i0, cnt in spans:
+                out[i0:i0 + cnt] = part["host"][off:off + cnt]
+            part["users"] -= 1
+            if part["users"] == 0:
+                PINNED.release(part["host"])
+                part["ids"] = None
+        ticket["parts"] = []
+        ticket["frames"] = None
+        return out
 
     def set_profiling(self, mode):
         _native.check(self.lib.vtd_trocr_set_profiling(self.handle, int(mode)), "vtd_trocr_set_profiling")

@@ -225,8 +225,8 @@ class TextRecognizer:
         if len(boxes) == 0:
             return None
         if self.use_transformer:
-            # only the encoder pass is enqueued here (asynchronous); the decode runs when the ticket is finished -- by then the NEXT
-            # batch's encoder pass is already queued on this stream and overlaps it (engine.TrOCREngine.submit_crops / finish)
+            # the crops are only queued here; the GPU work starts when a result is asked for, and then every queued ticket shares
+            # one encoder pass and one decode (engine.TrOCREngine.submit_crops / finish)
             return {"transformer": self.model.engine().submit_crops(frames, [tuple(int(v) for v in b) for b in boxes])}
         eng = self.model.engine()
         if getattr(self, "_id2char_dev", None) is None:
