@@ -19,14 +19,18 @@ timeout -k 10 300 python tools/trocr_stage_bench.py > $out/trocr_stages.log 2>&1
 tail -3 $out/trocr_stages.log
 timeout -k 10 500 python bench.py --recognizer trocr --steps 8 --warmup 2 --cpu-seconds 0 > $out/bench_r18_trocr_b32.json 2> $out/bench_r18_trocr_b32.err || { tail -5 $out/bench_r18_trocr_b32.err; exit 1; }
 cut -c1-200 $out/bench_r18_trocr_b32.json
-VTD_TROCR_MAX_CROPS=1024 timeout -k 10 500 python bench.py --recognizer trocr --batch 64 --steps 6 --warmup 2 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_r18_trocr_b64.json 2> $out/bench_r18_trocr_b64.err || { tail -5 $out/bench_r18_trocr_b64.err; exit 1; }
+timeout -k 10 500 python bench.py --recognizer trocr --batch 64 --steps 6 --warmup 2 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_r18_trocr_b64.json 2> $out/bench_r18_trocr_b64.err || { tail -5 $out/bench_r18_trocr_b64.err; exit 1; }
 cut -c1-200 $out/bench_r18_trocr_b64.json
 timeout -k 10 900 python bench.py --backbone resnet50 --recognizer trocr --mixed --steps 8 --warmup 2 --cpu-seconds 12 > $out/bench_cfg4_b32.json 2> $out/bench_cfg4_b32.err || { tail -5 $out/bench_cfg4_b32.err; exit 1; }
 cut -c1-200 $out/bench_cfg4_b32.json
-VTD_TROCR_MAX_CROPS=1024 timeout -k 10 600 python bench.py --backbone resnet50 --recognizer trocr --mixed --batch 64 --steps 6 --warmup 2 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_cfg4_b64.json 2> $out/bench_cfg4_b64.err || { tail -5 $out/bench_cfg4_b64.err; exit 1; }
+timeout -k 10 600 python bench.py --backbone resnet50 --recognizer trocr --mixed --batch 64 --steps 6 --warmup 2 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_cfg4_b64.json 2> $out/bench_cfg4_b64.err || { tail -5 $out/bench_cfg4_b64.err; exit 1; }
 cut -c1-200 $out/bench_cfg4_b64.json
 timeout -k 10 300 python bench.py --backbone resnet50 --workload detector --cpu-seconds 0 --sustain-seconds 0 --layers-out $out/layers_r50.json > $out/bench_r50_det.json 2> $out/bench_r50_det.err || { tail -5 $out/bench_r50_det.err; exit 1; }
 cut -c1-160 $out/bench_r50_det.json
+timeout -k 10 300 python bench.py --upload --cpu-seconds 0 > $out/bench_full_upload.json 2> $out/bench_full_upload.err || { tail -5 $out/bench_full_upload.err; exit 1; }
+cut -c1-160 $out/bench_full_upload.json
+VTD_TROCR_MERGE=0 timeout -k 10 500 python bench.py --recognizer trocr --steps 8 --warmup 2 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_r18_trocr_b32_unmerged.json 2> $out/bench_r18_trocr_b32_unmerged.err || { tail -5 $out/bench_r18_trocr_b32_unmerged.err; exit 1; }
+cut -c1-160 $out/bench_r18_trocr_b32_unmerged.json
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -o run -- python3 $R/bench.py --cpu-seconds 0 --sustain-seconds 0 --no-profile > $R/$out/stats.log 2>&1 || { tail -5 $R/$out/stats.log; exit 1; }
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats_trocr -o run -- python3 $R/bench.py --recognizer trocr --steps 4 --warmup 1 --cpu-seconds 0 --sustain-seconds 0 --no-profile > $R/$out/stats_trocr.log 2>&1 || { tail -5 $R/$out/stats_trocr.log; exit 1; }

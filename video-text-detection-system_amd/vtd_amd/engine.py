@@ -443,7 +443,7 @@ class TrOCREngine(_Tunable):
         from .trocr_spec import hf4_key
         self.lib = _native.require()
         self.spec = spec
-        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "64"))
+        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~40 MB of HBM each)
         self.lock = threading.Lock()
         cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
                                   int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
