@@ -46,15 +46,15 @@ def test_head_entry_half_halo_schedule_is_hazard_free_and_complete():
     the other half is multiplied.  The host-built schedule (no GPU needed) must (a) pass its own replay -- no half halo read
     before two steps after its fetch, none refilled while a later half-step still wants its content --, (b) visit every
     (K-step, channel half) of the head_entry_halo256 step table exactly once with the right weight columns, and (c) keep the
-    half halos alternating.  Internal C++ entry points, looked up by their mangled names."""
+    half halos alternating.  Internal helpers, exported with C linkage for this test."""
     import numpy as np
     import pytest
     lib = ctypes.CDLL(_native.LIB_PATH)
-    if not hasattr(lib, "_Z28vtd_head_entry_half_schedulePKiiPi"):
+    if not hasattr(lib, "vtd_head_entry_half_schedule"):
         pytest.skip("head_entry_half (csrc/experimental/) is only in an instrumented build: VTD_LIB_VARIANT=<tag> "
                     "VTD_EXTRA_HIPCC_FLAGS=-DVTD_EXPERIMENTAL_CANDIDATES")
-    steps_fn = getattr(lib, "_Z25vtd_head_entry_halo_stepsiiiPi")
-    sched_fn = getattr(lib, "_Z28vtd_head_entry_half_schedulePKiiPi")
+    steps_fn = lib.vtd_head_entry_halo_steps
+    sched_fn = lib.vtd_head_entry_half_schedule
     for nch1 in (1, 4):                      # C2 of 64 (ResNet-18) / 256 (ResNet-50) channels
         ns = 25 * nch1 + 36
         for cls in range(4):

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void head_entry_half_kernel(const HeadHalfP
 // {k offset, tap row offset | first << 8 | src << 9 | chunk << 12 | tap column << 16}, groups opened by `first`).
 // out[s] = {d0, d1, k0 | k1 << 16, aux}; returns 0, or a negative code if the replay finds a hazard (never for the shapes the
 // launcher admits; the check is what the parity tests lean on for the asynchronous part).
-int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out /* [nsteps][4] */) {
+extern "C" int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out /* [nsteps][4] */) {
     struct Half { int koff, tapoff, dx, group, half; };
     std::vector<Half> hs;
     std::vector<int> gsrc, gchunk, gstart, gcount;

@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
 
 // Step table of one interior class (py, px): entries {k offset into the [64][K] class matrix, tapoff | first<<8 | src<<9 | chunk<<12 | tap column<<16}.
 // nch1 = C2 channels / 64.  Returns the number of steps (25*nch1 + 36).
-int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36)*2] */) {
+// (extern "C": tests/test_abi.py replays the schedules on the host and looks the helper up by name)
+extern "C" int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out /* [(25*nch1+36)*2] */) {
     int s = 0;
     const int c2ch = nch1 * 64;
     for (int ch = 0; ch < nch1; ++ch)

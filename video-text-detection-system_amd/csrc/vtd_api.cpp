@@ -25,12 +25,12 @@ int vtd_launch_maxpool(const TensorDesc& in, const TensorDesc& out, int n, int k
                        hipStream_t stream);
 void vtd_stem_pool_pack_weights(const float* w_folded, half_t* packed);
 int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half_t* w_packed, const float* bias, int n, hipStream_t stream);
-int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
+extern "C" int vtd_head_entry_halo_steps(int py, int px, int nch1, int* out);
 int vtd_launch_head_entry_halo(const ConvParams& c, const int* steps_dev, int nsteps, int big_tiles, hipStream_t stream);
 #ifdef VTD_EXPERIMENTAL_CANDIDATES
 // csrc/experimental/: measured, parity-green, LOSING candidates of the composed head entry.  They are not part of the
 // product library: only an instrumented build (VTD_LIB_VARIANT=<tag> VTD_EXTRA_HIPCC_FLAGS=-DVTD_EXPERIMENTAL_CANDIDATES) carries them.
-int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out);
+extern "C" int vtd_head_entry_half_schedule(const int* steps, int nsteps, int* out);
 int vtd_launch_head_entry_half(const ConvParams& c, const int* sched_dev, int nsteps, hipStream_t stream);
 int vtd_head_entry_pair_tables(int py, int px, int c2ch, int* half_steps, int* plan);
 int vtd_launch_head_entry_pair(const ConvParams& c, const int* half_steps_dev, const int* plan_dev, int nh, hipStream_t stream);

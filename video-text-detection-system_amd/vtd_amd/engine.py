@@ -588,8 +588,7 @@ class TrOCREngine(_Tunable):
         if not queue:
             return
         rows = [(t, i) for t in queue for i in range(len(t["boxes"]))]
-        for t in queue:
-            t["parts"] = []
+        parts = {id(t): [] for t in queue}
         stream = queue[-1]["stream"]
         for start in range(0, len(rows), self.max_crops):
             chunk = rows[start:start + self.max_crops]
@@ -623,10 +622,11 @@ class TrOCREngine(_Tunable):
             for t in queue:
                 mine = [(o, i0, n) for (st, o, i0, n) in t.get("spans", []) if st == start]
                 if mine:
-                    t["parts"].append((part, mine))
+                    parts[id(t)].append((part, mine))
                     part["users"] += 1
-        for t in queue:
+        for t in queue:             # only now are the tickets marked as run: an exception above leaves them unmarked
             t.pop("spans", None)    # (a ticket keeps its frames until it is finished: the processor launches read them asynchronously)
+            t["parts"] = parts[id(t)]
 
     def finish(self, ticket):
         """ids [n, max_length] int32 (cpu) of a ticket, rows in the order of its boxes.  Flushes the queue when the ticket is still in
@@ -634,6 +634,8 @@ class TrOCREngine(_Tunable):
         with self.lock:
             if ticket["parts"] is None:
                 self._flush()
+        if ticket["parts"] is None:    # its pass raised half way (the exception went to whoever triggered the flush)
+            raise _native.NativeError("the recogniser pass this ticket was queued for failed")
         n = len(ticket["boxes"])
         out = torch.empty((n, self.spec.max_length), dtype=torch.int32)
         for part, spans in ticket["parts"]:
