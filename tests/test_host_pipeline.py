@@ -168,3 +168,33 @@ def test_quiet_gc_hands_the_heap_back_and_respects_a_host_freeze(monkeypatch):
                                              # may shrink: frozen objects are still freed by reference counting)
     finally:
         gc.unfreeze()
+
+
+def test_mixed_size_batches_come_back_in_frame_order(pipe):
+    """_pipeline_push groups a batch by frame shape (one device pass per size, cut to the engine's max_batch), the jobs ride the
+    three-deep pipeline, and every pushed batch is handed back whole and in frame order when its last group retires.  Host logic only:
+    the device halves are stubbed."""
+    class _Eng:
+        max_batch = 2
+
+    class _Model:
+        def engine(self):
+            return _Eng()
+
+    pipe.detector.model = _Model()
+    pipe._upload = object()
+    pipe._bind_device = lambda: None
+    pipe._stage = lambda chunk: (list(chunk), None)
+    pipe.submit_detection = lambda batch: {"batch": batch}
+    pipe._try_recognition = lambda job: job.setdefault("rec", True)
+    pipe.collect = lambda job, info: [{"frame_number": n, "timestamp": t, "detections": [], "shape": tuple(f.shape)}
+                                      for (n, t), f in zip(info, job["batch"])]
+    sizes = [(4, 6), (8, 6), (4, 6), (4, 6), (8, 6), (2, 2), (4, 6)]
+    frames = [np.zeros((h, w, 3), np.uint8) for h, w in sizes]
+    assert [len(g) for g in pipe._shape_groups(frames)] == [4, 2, 1]
+    out = pipe._pipeline_push(frames[:5], [(i, i / 10) for i in range(5)])      # 3 + 2 frames -> jobs of 2, 1, 2
+    out += pipe._pipeline_push(frames[5:], [(i, i / 10) for i in range(5, 7)])  # 2 more jobs
+    out += pipe._pipeline_drain()
+    assert [r["frame_number"] for r in out] == list(range(7))
+    assert [r["shape"][:2] for r in out] == sizes
+    assert pipe.route_counts == {"device": 7, "reference": 0}
