@@ -30,8 +30,9 @@ for name, N, K in shapes:
     bias = torch.zeros(N, device="cuda")
     out = torch.empty((M, N), device="cuda", dtype=torch.float16)
     s = torch.cuda.current_stream()
-    for order in ("0", "1"):
+    for order, var in (("1", "0"), ("1", "4"), ("1", "0"), ("1", "4")):
         os.environ["VTD_DGM_ORDER"] = order
+        os.environ["VTD_DGM_VARIANT"] = var
         for _ in range(3):
             rc = fn(A.data_ptr(), K, W.data_ptr(), N, bias.data_ptr(), out.data_ptr(), N, M, N, K, EPI_OUT_F16, s.cuda_stream)
             assert rc == 0, rc
@@ -45,4 +46,4 @@ for name, N, K in shapes:
         rows = torch.tensor([0, 1, 255, 256, 70000, M - 1], device="cuda")
         ref = (A[rows].double() @ W.double().T).float()
         err = float((out[rows].float() - ref).abs().max())
-        print(f"{name:6s} N={N:5d} K={K:5d} order={order}: {ms * 1e3:8.1f} us  {2 * M * N * K / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  max err {err:.3e}")
+        print(f"{name:6s} N={N:5d} K={K:5d} order={order} variant={var}: {ms * 1e3:8.1f} us  {2 * M * N * K / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  max err {err:.3e}")

@@ -86,7 +86,7 @@ __device__ __forceinline__ bool dgm_locate(const DenseGemmParams& p, int vb, int
     return true;
 }
 
-template <bool GELU>
+template <bool GELU, int VAR = 0>   // VAR (measurement only, tools/dense_gemm_bench.py): 1 = wave groups in phase, 2 = no s_setprio
 __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dgm_smem[];
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
@@ -117,6 +117,22 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
     auto issue = [&](const DgmTile& t, int stage, int slot) {   // K offset 32 stage of tile t into ring slot `slot`
         char* base = dgm_smem + slot * DGM_STAGE;
         const int k = stage * DGM_BK;
+        if constexpr ((VAR & 4) != 0) {
+            // TIMING EXPERIMENT ONLY (wrong results): every piece reads 1 KB of CONTIGUOUS memory (eight full 128-byte lines) instead of
+            // sixteen 64-byte half lines -- same instruction count, same bytes: does the half-line gather cost anything?
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half_t* a = p.A + (int64_t)t.m0 * p.lda + ((int64_t)(stage * 16 + w + 8 * i) * 512 + lane * 8);
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)a, (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int n0c = t.n0 < p.w_rows - 256 ? t.n0 : 0;
+                const half_t* bsrc_ = p.W + (int64_t)n0c * p.K + ((int64_t)(stage * 16 + w + 8 * i) * 512 + lane * 8);
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)bsrc_, (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.A + (t.a[i] + k)), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
     issue(cur, 2, 2);
     dgm_wait_vmcnt<8>();          // this wave's pieces of stage 0 have landed (stages 1, 2 stay in flight)
     dgm_barrier();                // hw barrier 0: stage 0 is published
-    if (wm == 1) dgm_barrier();   // group 1 runs one interval behind group 0 from here on
+    if ((VAR & 1) == 0 && wm == 1) dgm_barrier();   // group 1 runs one interval behind group 0 from here on
 
     half8 af[8], bf[4];
     bool have_prev = false;
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             // after its MFMAs of the MM interval of stage g - 1 -- which consume those fragments -- had been issued.
             if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1));
             else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1));
-            __builtin_amdgcn_s_setprio(1);
+            if ((VAR & 2) == 0) __builtin_amdgcn_s_setprio(1);
             if (s == 0) {   // a tile's first stage starts its accumulators
                 const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if ((VAR & 2) == 0) __builtin_amdgcn_s_setprio(0);
             dgm_barrier();
         }
         have_prev = true;
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
         cur = nxt;
         vb = vb2;
     }
-    if (wm == 0) dgm_barrier();   // group 0 pays back group 1's extra barrier (every wave executes the same number of barriers)
+    if ((VAR & 1) == 0 && wm == 0) dgm_barrier();   // group 0 pays back group 1's extra barrier (every wave executes the same number of barriers)
     epilogue(prev_m0, prev_n0);
 }
 
@@ -295,7 +311,20 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     int grid = 256;   // one persistent workgroup per CU; fewer when there are fewer tiles (always a multiple of 8)
     if (const char* e = std::getenv("VTD_DGM_GRID")) grid = std::max(8, std::atoi(e) / 8 * 8);
     if (nvb < grid) grid = (int)nvb;
-    if (flags & EPI_GELU) hipLaunchKernelGGL(dense_gemm_kernel<true>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+    int var = 0;
+    if (const char* e = std::getenv("VTD_DGM_VARIANT")) var = std::atoi(e);
+    if (var && !(flags & EPI_GELU)) {   // A/B measurements of the loop structure (never selected by the product)
+        static bool attr2 = false;
+        if (!attr2) {
+            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+            attr2 = true;
+        }
+        if (var == 1) hipLaunchKernelGGL((dense_gemm_kernel<false, 1>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+        else if (var == 4) hipLaunchKernelGGL((dense_gemm_kernel<false, 4>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+        else hipLaunchKernelGGL((dense_gemm_kernel<false, 2>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+    } else if (flags & EPI_GELU) hipLaunchKernelGGL(dense_gemm_kernel<true>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
     else hipLaunchKernelGGL(dense_gemm_kernel<false>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
     return -(int)hipGetLastError();
 }
