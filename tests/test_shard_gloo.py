@@ -257,3 +257,22 @@ def test_rank0_tuning_table_reaches_every_rank(tmp_path):
     t0 = json.load(open(tmp_path / "tuning_rank0.json"))
     t1 = json.load(open(tmp_path / "tuning_rank1.json"))
     assert t0 == t1 == ["conv|a|n4 3\n", "conv|b|n8 100\n"]
+
+
+def test_frame_source_skips_the_frames_of_other_ranks(tmp_path):
+    """VideoProcessor.set_shard: numbering and timestamps stay whole-clip, the frames of other ranks come out as None without being
+    read, set_shard(0, 1) restores the plain source (the rank-aware process_video sets and resets it)."""
+    from vtd_amd.video import VideoProcessor
+    frames = np.arange(9 * 4 * 6 * 3, dtype=np.uint8).reshape(9, 4, 6, 3)
+    clip = str(tmp_path / "c.npy")
+    np.save(clip, frames)
+    open(clip + ".json", "w").write(json.dumps({"fps": 30.0}))   # interval 3: source frames 0, 3, 6
+    vp = VideoProcessor()
+    whole = list(vp.extract_frames_at_fps(clip, 10))
+    assert [(n, round(t, 6)) for _, n, t in whole] == [(0, 0.0), (1, 0.1), (2, 0.2)] and all(f is not None for f, _, _ in whole)
+    vp.set_shard(1, 2)
+    mine = list(vp.extract_frames_at_fps(clip, 10))
+    assert [(f is None, n, round(t, 6)) for f, n, t in mine] == [(True, 0, 0.0), (False, 1, 0.1), (True, 2, 0.2)]
+    assert np.array_equal(mine[1][0], frames[3])
+    vp.set_shard(0, 1)
+    assert all(f is not None for f, _, _ in vp.extract_frames_at_fps(clip, 10))

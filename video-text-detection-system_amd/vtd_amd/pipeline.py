@@ -86,8 +86,9 @@ class VideoTextPipeline:
         only its own frames through its device pipeline, and once per round of W x batch_size frames the ranks exchange
         their finished results in ONE all_gather of a padded block (vtd_amd/shard.py, RCCL on its own stream).  Rank 0
         returns the merged result ordered by frame number -- identical to the single-GPU result; the other ranks return
-        rank 0's summary (broadcast at the end) and video_info with an empty 'results' list.  Every rank reads the whole clip
-        from its frame source and keeps only its own frames (the source decides whether skipped frames cost a decode).  A rank
+        rank 0's summary (broadcast at the end) and video_info with an empty 'results' list.  Every rank walks the whole clip
+        (numbering and timestamps are whole-clip); a source with ``set_shard`` (vtd_amd.video.VideoProcessor) hands the frames of
+        other ranks out as None without reading them, any other source is simply filtered here.  A rank
         that fails tells the others at their next sequence point (shard.ResultGather: error flag in the capacity
         all_reduce), so all ranks return 'failed' together instead of waiting in a collective."""
         gather = None
@@ -108,6 +109,9 @@ class VideoTextPipeline:
                 import torch.distributed as dist
                 world, rank = dist.get_world_size(), dist.get_rank()
                 gather = shard.ResultGather()
+                if hasattr(self.video_processor, "set_shard"):   # frames of other ranks come out as None, unread (numbering stays whole-clip)
+                    self.video_processor.set_shard(rank, world)
+                    quiet.callback(self.video_processor.set_shard, 0, 1)
             seen = 0          # frames of the current round seen by every rank (W x batch_size closes a round)
 
             loop = asyncio.get_event_loop()

@@ -29,6 +29,13 @@ class _NpySource:
 class VideoProcessor:
     def __init__(self):
         self.supported_formats = [".mp4", ".avi", ".mov", ".mkv", ".wmv", ".npy"]
+        self._shard = (0, 1)
+
+    def set_shard(self, rank: int, world: int):
+        """Rank-aware video loop (one process per GPU): sampled frame i belongs to rank i mod world.  Frames of other ranks are still
+        counted -- numbering and timestamps stay those of the whole clip -- but come out as ``None`` without being materialised
+        (`.npy`: not read; OpenCV: ``grab()`` without ``retrieve()``, i.e. no colour conversion / copy).  ``set_shard(0, 1)`` resets."""
+        self._shard = (int(rank), max(1, int(world)))
 
     def _open(self, video_path):
         if str(video_path).endswith(".npy"):
@@ -71,17 +78,24 @@ class VideoProcessor:
                 import cv2
                 source_fps = src.get(cv2.CAP_PROP_FPS)
             interval = max(1, int(source_fps / target_fps))
+            rank, world = self._shard
             frame_number = extracted = 0
             while True:
+                sampled = frame_number % interval == 0
+                mine = sampled and extracted % world == rank
                 if npy:
                     if frame_number >= len(src.frames):
                         break
-                    frame = np.ascontiguousarray(src.frames[frame_number]) if frame_number % interval == 0 else None
-                else:
+                    frame = np.ascontiguousarray(src.frames[frame_number]) if mine else None
+                elif mine:
                     ok, frame = src.read()
                     if not ok:
                         break
-                if frame_number % interval == 0:
+                else:
+                    frame = None
+                    if not src.grab():
+                        break
+                if sampled:
                     yield frame, extracted, frame_number / source_fps
                     extracted += 1
                 frame_number += 1
