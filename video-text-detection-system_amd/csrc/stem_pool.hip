@@ -15,6 +15,7 @@
 //     160x160x64 map is written to HBM (105 MB instead of 420 + 105 MB).
 // Patches arrive by LDS-DMA through a 3-deep ring, two tiles ahead of the maths (round 1 fetched one tile ahead into registers
 // and consumed it right after the MFMA loop: the launch ran at the load latency), and each XCD sweeps its own eighth of the tiles.
+#include <cstdlib>
 #include "vtd_common.h"
 
 namespace {
@@ -35,6 +36,7 @@ struct StemPoolParams {
     half_t* out;         // [n][out_hp][out_wp][64], ring out_ring
     int n, in_hp, in_wp, conv_h, conv_w, pool_h, pool_w, out_hp, out_wp, out_ring;
     int tiles_x, tiles_y, total_tiles;
+    int dbg;             // VTD_STEM_EXPERIMENT builds only (tools/stem_experiment.sh): timing variants, results are garbage
 };
 
 template <int N>
@@ -107,6 +109,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         u_col[k] = 2 * (u - u_row[k] * 20);
     }
     auto issue = [&](int tile, int stage) {
+#ifdef VTD_STEM_EXPERIMENT
+        if (p.dbg == 4) return;
+#endif
         int img, py0, px0;
         sp_tile_coords(p, __builtin_amdgcn_readfirstlane(tile), img, py0, px0);
         const half_t* base = p.in + (int64_t)img * p.in_hp * p.in_wp * 4;
@@ -149,6 +154,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) af[(ky + 1) & 1][j] = *(const half8*)(pb + a_off[j] + (ky + 1) * (SP_PATCH_COLS * 8));
             }
+#ifdef VTD_STEM_EXPERIMENT
+            if (p.dbg == 3 && ky > 0) { for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(af[ky & 1][j])); continue; }
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -157,6 +165,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         }
 
         // ReLU (packed, after the fp16 convert), zero outside the conv map, -> LDS conv tile (lane: 4 consecutive channels of one pixel)
+#ifdef VTD_STEM_EXPERIMENT
+        if (p.dbg == 2) {  // neither the conv tile nor the pool: keep the accumulators alive
+            float t = 0.f;
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (t == 123.456f) p.out[0] = (half_t)t;
+            if (k + 2 < nt) sp_wait_vmcnt<3>(); else sp_wait_vmcnt<0>();
+            sp_lds_barrier();
+            st = st + 1 == SP_NST ? 0 : st + 1;
+            continue;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pix = wv * 64 + j * 16 + fr;
@@ -177,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         sp_lds_barrier();
 
         // 3x3/s2 max over the conv tile: item = (pooled pixel, 8-channel group)
+#ifdef VTD_STEM_EXPERIMENT
+        if (p.dbg != 1)
+#endif
         for (int item = tid; item < SP_PT_ROWS * SP_PT_COLS * 8; item += 256) {
             // A wave's 64 items are one pooled row: 8 pixels x 8 channel groups.  Which lane takes which matters: ds_read_b128 is
             // served in four fixed 16-lane groups and with cg = lane & 7 each group hit its banks 2.75 times (11 LDS cycles per
@@ -194,6 +216,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
                         if (r == 0 && s == 0) continue;
                         m = __builtin_elementwise_max(m, *(const half8*)(src + (r * SP_CT_COLS + s) * SP_CT_PITCH));
                     }
+#ifdef VTD_STEM_EXPERIMENT
+                if (p.dbg == 5) { asm volatile("" ::"v"(m)); continue; }  // everything but the stores
+#endif
                 *(half8*)(p.out + (((int64_t)img * p.out_hp + py + p.out_ring) * p.out_wp + px + p.out_ring) * 64 + cg * 8) = m;
             }
         }
@@ -236,6 +261,10 @@ int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half
     p.tiles_x = out.w / SP_PT_COLS;
     p.tiles_y = (out.h + SP_PT_ROWS - 1) / SP_PT_ROWS;
     p.total_tiles = n * p.tiles_x * p.tiles_y;
+    p.dbg = 0;
+#ifdef VTD_STEM_EXPERIMENT
+    if (const char* e = getenv("VTD_STEM_DEBUG")) p.dbg = atoi(e);
+#endif
     const int grid = p.total_tiles < 512 ? p.total_tiles : 512;  // 2 resident workgroups per CU, persistent over tiles
     static bool attr_set = false;
     if (!attr_set) {
