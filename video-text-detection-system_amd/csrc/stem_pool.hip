@@ -36,8 +36,16 @@ struct StemPoolParams {
     half_t* out;         // [n][out_hp][out_wp][64], ring out_ring
     int n, in_hp, in_wp, conv_h, conv_w, pool_h, pool_w, out_hp, out_wp, out_ring;
     int tiles_x, tiles_y, total_tiles;
-    int dbg;             // VTD_STEM_EXPERIMENT builds only (tools/stem_experiment.sh): timing variants, results are garbage
 };
+
+// Post-ReLU fp16 values are >= +0, so their bit patterns order like int16: the pool (and the ReLU itself: every negative half, -0
+// included, is a negative int16) run on v_pk_max_i16.  The float form costs twice the instructions: llvm's maxnum quiets each
+// operand first (v_pk_max_f16 x, x, x), 68 instead of 32 per pooled item.
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8 sp_max(half8 a, half8 b) {
+    return __builtin_bit_cast(half8, __builtin_elementwise_max(__builtin_bit_cast(short8v, a), __builtin_bit_cast(short8v, b)));
+}
 
 template <int N>
 __device__ __forceinline__ void sp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -56,6 +64,10 @@ __device__ __forceinline__ void sp_tile_coords(const StemPoolParams& p, int tile
     px0 = (r - ty * p.tiles_x) * SP_PT_COLS;
 }
 
+// DBG: timing-only variants for tools/stem_experiment.sh (compile-time, so the product instantiation DBG = 0 is untouched;
+// results of the others are garbage): 1 no pool, 2 neither conv tile nor pool, 3 one of seven kernel rows, 4 no loads, 5 no stores,
+// 6 MFMA phase at raised priority, 7 = 6 + the CU's second workgroup starts late, 8 late start only (6..8 compute the real result)
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     unsigned char* const ring = sp_smem;                                 // [SP_NST][SP_PATCH_BYTES]
@@ -109,9 +121,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         u_col[k] = 2 * (u - u_row[k] * 20);
     }
     auto issue = [&](int tile, int stage) {
-#ifdef VTD_STEM_EXPERIMENT
-        if (p.dbg == 4) return;
-#endif
+        if constexpr (DBG == 4) return;
         int img, py0, px0;
         sp_tile_coords(p, __builtin_amdgcn_readfirstlane(tile), img, py0, px0);
         const half_t* base = p.in + (int64_t)img * p.in_hp * p.in_wp * 4;
@@ -125,6 +135,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         }
     };
 
+    if constexpr (DBG == 7 || DBG == 8) {  // the second workgroup of a CU (by dispatch order: a guess, for speed only) starts half a tile late
+        if (((blockIdx.x >> 3) & 32) != 0) { __builtin_amdgcn_s_sleep(60); }
+    }
     issue(first, 0);
     if (nt > 1) { issue(first + stride, 1); sp_wait_vmcnt<3>(); } else sp_wait_vmcnt<0>();
     sp_lds_barrier();
@@ -148,25 +161,28 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         half8 af[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[0][j] = *(const half8*)(pb + a_off[j]);
+        if constexpr (DBG == 6 || DBG == 7) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
             if (ky < 6) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) af[(ky + 1) & 1][j] = *(const half8*)(pb + a_off[j] + (ky + 1) * (SP_PATCH_COLS * 8));
             }
-#ifdef VTD_STEM_EXPERIMENT
-            if (p.dbg == 3 && ky > 0) { for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(af[ky & 1][j])); continue; }
-#endif
+            if (DBG == 3 && ky > 0) { for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(af[ky & 1][j])); continue; }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[ky][i], af[ky & 1][j], acc[i][j], 0, 0, 0);
+            // pin the order inside the block: the four reads of the next kernel row FIRST, then the 16 MFMAs (left alone, hipcc put
+            // the reads behind 12 of them and waited for them 4 MFMAs later: ~100 exposed cycles per kernel row)
+            if (ky < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if constexpr (DBG == 6 || DBG == 7) __builtin_amdgcn_s_setprio(0);
         // ReLU (packed, after the fp16 convert), zero outside the conv map, -> LDS conv tile (lane: 4 consecutive channels of one pixel)
-#ifdef VTD_STEM_EXPERIMENT
-        if (p.dbg == 2) {  // neither the conv tile nor the pool: keep the accumulators alive
+        if constexpr (DBG == 2) {  // neither the conv tile nor the pool: keep the accumulators alive
             float t = 0.f;
             for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
             if (t == 123.456f) p.out[0] = (half_t)t;
@@ -175,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
             st = st + 1 == SP_NST ? 0 : st + 1;
             continue;
         }
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pix = wv * 64 + j * 16 + fr;
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
                 half4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[i][j][e];
-                hv = __builtin_elementwise_max(hv, half4{0, 0, 0, 0});
+                hv = __builtin_bit_cast(half4, __builtin_elementwise_max(__builtin_bit_cast(short4v, hv), short4v{0, 0, 0, 0}));
                 if (!valid) hv = half4{0, 0, 0, 0};
                 *(half4*)(dst + i * 32) = hv;
             }
@@ -196,30 +211,34 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         sp_lds_barrier();
 
         // 3x3/s2 max over the conv tile: item = (pooled pixel, 8-channel group)
-#ifdef VTD_STEM_EXPERIMENT
-        if (p.dbg != 1)
-#endif
-        for (int item = tid; item < SP_PT_ROWS * SP_PT_COLS * 8; item += 256) {
-            // A wave's 64 items are one pooled row: 8 pixels x 8 channel groups.  Which lane takes which matters: ds_read_b128 is
-            // served in four fixed 16-lane groups and with cg = lane & 7 each group hit its banks 2.75 times (11 LDS cycles per
-            // read, SQ_LDS_BANK_CONFLICT); with this assignment the 16 chunks of a group fall on 16 different bank quads.
-            const int qy = item >> 6, cg = (item >> 2) & 7;
-            const int qx = ((item >> 5) & 1) | ((item & 3) << 1);
-            const int py = py0 + qy, px = px0 + qx;
-            if (py < p.pool_h && px < p.pool_w) {
-                const unsigned char* src = ctile + ((2 * qy) * SP_CT_COLS + 2 * qx) * SP_CT_PITCH + cg * 16;
-                half8 m = *(const half8*)src;
+        // A wave's 64 items are one pooled row: 8 pixels x 8 channel groups; waves 0..2 own two rows (7 rows in all).  Which lane takes
+        // which matters: ds_read_b128 is served in four fixed 16-lane groups and with cg = lane & 7 each group hit its banks 2.75
+        // times (11 LDS cycles per read, SQ_LDS_BANK_CONFLICT); with this assignment the 16 chunks of a group fall on 16 different
+        // bank quads.  All 9 window reads of an item leave before the first max: left to itself hipcc waited after every one to three
+        // reads, six dependent LDS round trips per item (~2.2 k of the ~9 k cycles of a tile).
+        if constexpr (DBG != 1) {
+            const int cg = (lane >> 2) & 7;
+            const int qx = ((lane >> 5) & 1) | ((lane & 3) << 1);
+            const bool two = wv < 3;  // wave-uniform: pooled rows wv and wv + 4
+            const unsigned char* src0 = ctile + ((2 * wv) * SP_CT_COLS + 2 * qx) * SP_CT_PITCH + cg * 16;
+            const int px = px0 + qx;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (it == 1 && !two) break;
+                const unsigned char* src = src0 + it * (8 * SP_CT_COLS * SP_CT_PITCH);
+                half8 v[9];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        if (r == 0 && s == 0) continue;
-                        m = __builtin_elementwise_max(m, *(const half8*)(src + (r * SP_CT_COLS + s) * SP_CT_PITCH));
-                    }
-#ifdef VTD_STEM_EXPERIMENT
-                if (p.dbg == 5) { asm volatile("" ::"v"(m)); continue; }  // everything but the stores
-#endif
-                *(half8*)(p.out + (((int64_t)img * p.out_hp + py + p.out_ring) * p.out_wp + px + p.out_ring) * 64 + cg * 8) = m;
+                    for (int c = 0; c < 3; ++c) v[r * 3 + c] = *(const half8*)(src + (r * SP_CT_COLS + c) * SP_CT_PITCH);
+                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);  // all nine reads in flight before the first max
+                half8 m = sp_max(v[0], v[1]);
+#pragma unroll
+                for (int q = 2; q < 9; ++q) m = sp_max(m, v[q]);
+                const int py = py0 + wv + 4 * it;
+                if (DBG == 5) asm volatile("" ::"v"(m));
+                else if (py < p.pool_h && px < p.pool_w)
+                    *(half8*)(p.out + (((int64_t)img * p.out_hp + py + p.out_ring) * p.out_wp + px + p.out_ring) * 64 + cg * 8) = m;
             }
         }
         // Tile k+1 must be in LDS for everyone after the barrier below.  Loads land in order, so it has landed once at most the 3
@@ -261,18 +280,35 @@ int vtd_launch_stem_pool(const TensorDesc& in, const TensorDesc& out, const half
     p.tiles_x = out.w / SP_PT_COLS;
     p.tiles_y = (out.h + SP_PT_ROWS - 1) / SP_PT_ROWS;
     p.total_tiles = n * p.tiles_x * p.tiles_y;
-    p.dbg = 0;
-#ifdef VTD_STEM_EXPERIMENT
-    if (const char* e = getenv("VTD_STEM_DEBUG")) p.dbg = atoi(e);
-#endif
     const int grid = p.total_tiles < 512 ? p.total_tiles : 512;  // 2 resident workgroups per CU, persistent over tiles
+    void (*kern)(const StemPoolParams) = stem_pool_kernel<0>;
+#ifdef VTD_STEM_EXPERIMENT
+    if (const char* e = getenv("VTD_STEM_DEBUG")) {
+        switch (atoi(e)) {
+            case 1: kern = stem_pool_kernel<1>; break;
+            case 2: kern = stem_pool_kernel<2>; break;
+            case 3: kern = stem_pool_kernel<3>; break;
+            case 4: kern = stem_pool_kernel<4>; break;
+            case 5: kern = stem_pool_kernel<5>; break;
+            case 6: kern = stem_pool_kernel<6>; break;
+            case 7: kern = stem_pool_kernel<7>; break;
+            case 8: kern = stem_pool_kernel<8>; break;
+            default: break;
+        }
+    }
+    {
+        hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+        if (ea != hipSuccess) return -(int)ea;
+    }
+#else
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ea = hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+        hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
         if (ea != hipSuccess) return -(int)ea;
         attr_set = true;
     }
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), SP_LDS, stream, p);
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SP_LDS, stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
