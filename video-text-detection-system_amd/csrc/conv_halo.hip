@@ -718,6 +718,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_duo_kernel(const HaloParam
                         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // Ask for the NEXT half-step's fragments here, 16 MFMAs after their reads left: the s_waitcnt lands where only those
+                    // eight reads are outstanding.  Left to itself hipcc waited for them in front of the MFMAs of the half-step after
+                    // -- as lgkmcnt(0), behind the eight reads issued just before: every second half-step sat out a full LDS round trip
+                    if (hs + 1 < 18) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fa[(hs + 1) & 1][j]));
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) asm volatile("" ::"v"(fb[(hs + 1) & 1][a]));
+                    }
                 }
             }
         } else {

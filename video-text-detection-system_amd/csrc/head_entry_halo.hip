@@ -363,7 +363,17 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
         if (s + HB_RING - 1 < p.nsteps) issue_b(k3, (stage + HB_RING - 1) & 3);
         const int tapoff = d_t;
         const bool next_same_group = s + 1 < p.nsteps && !((n_t >> 8) & 1);
-        if (!have_frags) load_frags(tapoff, stage, 0, fa[0], fb[0]);
+        // Where the waits for fragment reads go is decided HERE, by asking for the registers (an empty asm): hipcc's wait-count pass
+        // does not count LDS reads past a batch of eight -- it put s_waitcnt lgkmcnt(0) in front of the MFMAs of half 0, behind the
+        // eight reads of half 1 issued just above: every K-step sat out a full LDS round trip in the open and the prefetch was lost
+        // (ISA of the round-2 kernel).  Each batch is now waited for 16 MFMAs after it left and before anything younger is issued.
+        if (!have_frags) {  // first step of a halo group: nothing was prefetched, these reads are in the open
+            load_frags(tapoff, stage, 0, fa[0], fb[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fa[0][j]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fb[0][i]));
+        }
         // half 0: prefetch half 1 of this step
         load_frags(tapoff, stage, 1, fa[1], fb[1]);
 #pragma unroll
@@ -373,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void head_entry_halo256_kernel(const HeadHa
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fa[1][j]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fb[1][i]));
         // half 1: prefetch half 0 of the next step (same halo group only), then the descriptors of the steps after it
         if (next_same_group) load_frags(n_t, (stage + 1) & 3, 0, fa[0], fb[0]);
         v_k3 = raw_k(s + HB_RING);

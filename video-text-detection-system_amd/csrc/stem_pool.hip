@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
             unsigned char* dst = ctile + pix * SP_CT_PITCH + fq * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                half4 hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[i][j][e];
+                typedef float float2v __attribute__((ext_vector_type(2)));
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                const half2v lo = __builtin_convertvector((float2v{acc[i][j][0], acc[i][j][1]}), half2v);  // v_cvt_pk_f16_f32
+                const half2v hi = __builtin_convertvector((float2v{acc[i][j][2], acc[i][j][3]}), half2v);
+                half4 hv = half4{lo[0], lo[1], hi[0], hi[1]};
                 hv = __builtin_bit_cast(half4, __builtin_elementwise_max(__builtin_bit_cast(short4v, hv), short4v{0, 0, 0, 0}));
                 if (!valid) hv = half4{0, 0, 0, 0};
                 *(half4*)(dst + i * 32) = hv;
