@@ -405,7 +405,7 @@ def main():
             achieved = bytes_total / (ms * 1e-3) / 1e9
             traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")   # its largest launch: rows stated in traffic_detail
             detector_roofline = roofline
-            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
+            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
                         "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
@@ -513,7 +513,7 @@ def read_sclk_mhz():
 # launch-slot description (vtd_api.cpp: vtd_detector_get_profile) -> device kernel symbol of exactly that variant
 KERNEL_SYMBOLS = (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
                   ("head_entry_halo256", "head_entry_halo256_kernel<false>("), ("head_entry_halo ", "head_entry_halo_kernel<"),
-                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 4>("))
+                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 4"))
 
 
 def lookup_traffic(launch_name, profiles_dir=None):

@@ -241,7 +241,7 @@ struct DecAttnParams {
 // 110 us at 64 live rows, 0.17 of the HBM rate).  Now the workgroup covers 8 NW keys per round (eight lanes per 128-byte row), three
 // rounds are in flight per thread -- the score pass and the value pass are each two dependent batches of loads for 577 tokens at
 // NW = 16 -- and the partial sums meet through LDS in a fixed order (bitwise repeatable).
-template <bool SELF, int NW>
+template <bool SELF, int NW, int U>
 __global__ __launch_bounds__(64 * NW) void dec_attn_kernel(DecAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KR = 8 * NW;             // keys per round (eight lanes per 128-byte row)
@@ -268,7 +268,10 @@ __global__ __launch_bounds__(64 * NW) void dec_attn_kernel(DecAttnParams p) {
             *(half8*)(vb + (int64_t)(L - 1) * D) = vnew;
         }
     }
-    constexpr int U = 3;   // rounds in flight per thread
+    // U = rounds in flight per thread.  A pass is ceil(L / (8 NW U)) DEPENDENT batches of loads: with U = 3 the 577 encoder tokens were
+    // seven batches per pass (the seventh for one key), fourteen memory round trips per launch however few rows were live; U = 10
+    // makes it two per pass (40 registers of loads in flight per thread).  A thread's keys and their order do not depend on U:
+    // bit-identical outputs.  The self-attention (L <= 50) is one batch at U = 2.
     // ---- scores
     float mx = -INFINITY;
     for (int k0 = 0; k0 < L; k0 += KR * U) {
@@ -519,8 +522,9 @@ int vtd_launch_dec_attn(int self, const half_t* q, int ldq, half_t* kc, half_t* 
     // four waves per (row, head) for both (16 waves for the cross-attention, measured: 95 us against 45 us per launch at 64 live rows --
     // two 1024-thread workgroups per CU leave too few (row, head) units in flight)
     const size_t lds = (size_t)((L + 31) / 32 * 32 + 4 * 64) * 4;
-    if (self) hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(heads, M), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((dec_attn_kernel<false, 4>), dim3(heads, M), dim3(256), lds, s, p);
+    if (self && L <= 64) hipLaunchKernelGGL((dec_attn_kernel<true, 4, 2>), dim3(heads, M), dim3(256), lds, s, p);
+    else if (self) hipLaunchKernelGGL((dec_attn_kernel<true, 4, 4>), dim3(heads, M), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((dec_attn_kernel<false, 4, 10>), dim3(heads, M), dim3(256), lds, s, p);
     return -(int)hipGetLastError();
 }
 
