@@ -21,8 +21,9 @@ if fn is None:
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
 M = 287 * 577
-shapes = [("qkv", 2304, 768), ("o", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072), ("ck/cv", 1024, 768)]
+shapes = [("qkv", 2304, 768), ("o", 768, 768), ("fc1", 3072, 768), ("fc1+gelu", 3072, 768), ("fc2", 768, 3072), ("ck/cv", 1024, 768)]
 EPI_OUT_F16 = 32
+EPI_GELU = 64
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, N, K in shapes:
     A = (torch.rand((M, K), device="cuda", generator=g) * 2 - 1).half()
@@ -30,20 +31,28 @@ for name, N, K in shapes:
     bias = torch.zeros(N, device="cuda")
     out = torch.empty((M, N), device="cuda", dtype=torch.float16)
     s = torch.cuda.current_stream()
-    for order, var in (("1", "0"), ("1", "4"), ("1", "0"), ("1", "4")):
+    out0 = None
+    flags = EPI_OUT_F16 | (EPI_GELU if "gelu" in name else 0)
+    for order, var in tuple(("1", v) for v in os.environ.get("DGM_BENCH_VARIANTS", "0 8 16 0 8 16").split()):
         os.environ["VTD_DGM_ORDER"] = order
         os.environ["VTD_DGM_VARIANT"] = var
         for _ in range(3):
-            rc = fn(A.data_ptr(), K, W.data_ptr(), N, bias.data_ptr(), out.data_ptr(), N, M, N, K, EPI_OUT_F16, s.cuda_stream)
+            rc = fn(A.data_ptr(), K, W.data_ptr(), N, bias.data_ptr(), out.data_ptr(), N, M, N, K, flags, s.cuda_stream)
             assert rc == 0, rc
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            fn(A.data_ptr(), K, W.data_ptr(), N, bias.data_ptr(), out.data_ptr(), N, M, N, K, EPI_OUT_F16, s.cuda_stream)
+            fn(A.data_ptr(), K, W.data_ptr(), N, bias.data_ptr(), out.data_ptr(), N, M, N, K, flags, s.cuda_stream)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 10
         rows = torch.tensor([0, 1, 255, 256, 70000, M - 1], device="cuda")
-        ref = (A[rows].double() @ W.double().T).float()
+        ref = (A[rows].double() @ W.double().T)
+        if flags & EPI_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        ref = ref.float()
         err = float((out[rows].float() - ref).abs().max())
-        print(f"{name:6s} N={N:5d} K={K:5d} order={order} variant={var}: {ms * 1e3:8.1f} us  {2 * M * N * K / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  max err {err:.3e}")
+        if var == "0" and out0 is None:
+            out0 = out.clone()
+        same = "" if var in ("0", "4", "32", "64", "96") else f"  bitwise == variant 0: {bool(torch.equal(out, out0))}"
+        print(f"{name:6s} N={N:5d} K={K:5d} order={order} variant={var}: {ms * 1e3:8.1f} us  {2 * M * N * K / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  max err {err:.3e}{same}")

@@ -41,12 +41,12 @@ constexpr int DGM_GM = 8;
 template <int N>
 __device__ __forceinline__ void dgm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, branch-free: one rcp, one
-// exp, five fused multiply-adds) -- three orders of magnitude below the fp16 rounding of the value it produces; libdevice's erff
+// Exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 + one ulp of the reciprocal, branch-free: one v_rcp_f32,
+// one v_exp_f32, five fused multiply-adds) -- three orders of magnitude below the fp16 rounding of the value it produces; libdevice's erff
 // expands to a two-branch polynomial whose eight interleaved copies per row do not fit beside 128 accumulators.
 __device__ __forceinline__ float dgm_gelu(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp): __frcp_rn is the ten-instruction IEEE division
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
@@ -86,7 +86,9 @@ __device__ __forceinline__ bool dgm_locate(const DenseGemmParams& p, int vb, int
     return true;
 }
 
-template <bool GELU, int VAR = 0>   // VAR (measurement only, tools/dense_gemm_bench.py): 1 = wave groups in phase, 2 = no s_setprio
+template <bool GELU, int VAR = 0>   // VAR (tools/dense_gemm_bench.py): 1 = wave groups in phase, 2 = no s_setprio, 4 = contiguous fetch (timing only),
+                                    // 8 = all four LDS-DMA instructions of a stage in the R interval, 16 = the A pieces in R and the B pieces in MM,
+                                    // 32 = no LDS-DMA after the prologue, 64 = fragments read once (both timing only, wrong results)
 __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char dgm_smem[];
     const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             t.b[i] = n * p.K + chunk * 8;
         }
     };
-    auto issue = [&](const DgmTile& t, int stage, int slot) {   // K offset 32 stage of tile t into ring slot `slot`
+    int g = 0;                    // global stage counter of this workgroup: stage s of its t-th tile is g = t S + s, ring slot g & 3
+    auto issue = [&](const DgmTile& t, int stage, int slot, int part = 3) {   // K offset 32 stage of tile t into ring slot `slot` (part: 1 = A pieces, 2 = B pieces)
+        if constexpr ((VAR & 32) != 0) { if (g >= 1) return; }   // TIMING ONLY (wrong results): no operand traffic after the prologue
         char* base = dgm_smem + slot * DGM_STAGE;
         const int k = stage * DGM_BK;
         if constexpr ((VAR & 4) != 0) {
@@ -133,13 +137,21 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             }
             return;
         }
+        if (part & 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.A + (t.a[i] + k)), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.A + (t.a[i] + k)), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
+        }
+        if (part & 2) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.W + (t.b[i] + k)), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.W + (t.b[i] + k)), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
+        }
     };
+    // Where a stage's four LDS-DMA instructions are issued: PART_R of them in the R interval (behind the fragment reads, while the other
+    // wave of the SIMD multiplies), the rest at the top of the MM interval (in front of this wave's own 32 MFMAs, where nothing covers them)
+    constexpr int PART_R = (VAR & 8) ? 3 : (VAR & 16) ? 1 : 0, PART_MM = 3 & ~PART_R;
+    constexpr int N_R = (PART_R & 1 ? 2 : 0) + (PART_R & 2 ? 2 : 0);
 
     // ---- fragment read offsets (bytes inside a stage): A rows wm * 128 + 16 i + fr, B rows wn * 64 + 16 j + fr, logical chunk fq
     int a_off[8], b_off[4];
@@ -197,7 +209,6 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
     nxt = cur;
 
     const int S = p.K / DGM_BK;   // >= 4 (launcher)
-    int g = 0;                    // global stage counter of this workgroup: stage s of its t-th tile is g = t S + s, ring slot g & 3
     issue(cur, 0, 0);
     issue(cur, 1, 1);
     issue(cur, 2, 2);
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             const char* st = dgm_smem + (g & (DGM_NST - 1)) * DGM_STAGE;
             // Stage g + 1 must have landed before the barrier that ends this interval; stage g + 2 (issued in the previous MM) may stay
             // in flight.  Loads return in order, so "at most 4 outstanding" means stage g + 1 is in.
+            const bool more3 = s + 3 < S || has_next;   // stage g + 3 exists
             if (s == 0 && have_prev) {
                 // first stage of a new tile: the previous tile's accumulators leave from here, while the other wave of this SIMD
                 // multiplies.  The wait comes BEFORE the stores (they share the counter and retire in any order: behind them the same
@@ -226,23 +238,46 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
                 dgm_wait_vmcnt<4>();
                 epilogue(prev_m0, prev_n0);
                 __builtin_amdgcn_sched_barrier(0);
+                if ((VAR & 64) == 0 || g == 0) {   // (64: TIMING ONLY, fragments are read once)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) af[i] = *(const half8*)(st + a_off[i]);
+                }
+                if constexpr (PART_R != 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1), PART_R);
+                    else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1), PART_R);
+                }
             } else {
+                if ((VAR & 64) == 0 || g == 0) {   // (64: TIMING ONLY, fragments are read once)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) af[i] = *(const half8*)(st + a_off[i]);
-                if (s + 2 < S || has_next) dgm_wait_vmcnt<4>(); else dgm_wait_vmcnt<0>();
+                }
+                if constexpr (PART_R != 0) {
+                    // Ring slot (g + 3) & 3 = (g - 1) & 3 is restaged one interval EARLIER than in the MM placement: its last readers
+                    // were this group's R interval of stage g - 1 (two intervals ago) and the other group's, which ended at the barrier
+                    // just passed -- behind an s_waitcnt lgkmcnt(0) (below), so those reads are complete, not merely issued.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1), PART_R);
+                    else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1), PART_R);
+                    // stage g + 1 has landed when only stage g + 2 and what was just issued of stage g + 3 are outstanding
+                    if (more3) dgm_wait_vmcnt<4 + N_R>(); else if (s + 2 < S) dgm_wait_vmcnt<4>(); else dgm_wait_vmcnt<0>();
+                } else {
+                    if (s + 2 < S || has_next) dgm_wait_vmcnt<4>(); else dgm_wait_vmcnt<0>();
+                }
             }
+            if constexpr (PART_R != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are COMPLETE at the barrier
             dgm_barrier();
             // ---- interval MM: restage ring slot (g + 3) & 3 = (g - 1) & 3.  Its last readers were the R intervals of stage g - 1: this
             // group's ended two barriers ago, the other group's one barrier ago at the latest, and every wave reached that barrier only
             // after its MFMAs of the MM interval of stage g - 1 -- which consume those fragments -- had been issued.
-            if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1));
-            else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1));
+            if constexpr (PART_MM != 0) {
+                if (s + 3 < S) issue(cur, s + 3, (g + 3) & (DGM_NST - 1), PART_MM);
+                else if (has_next) issue(nxt, s + 3 - S, (g + 3) & (DGM_NST - 1), PART_MM);
+            }
             if ((VAR & 2) == 0) __builtin_amdgcn_s_setprio(1);
             if (s == 0) {   // a tile's first stage starts its accumulators
                 const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -296,12 +331,6 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
             if (p.tiles_n % g == 0) { p.gn = g; break; }
         p.blocks_n = p.tiles_n / p.gn;
     }
-    static bool attr = false;
-    if (!attr) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        attr = true;
-    }
     int64_t nvb = ((int64_t)p.tiles_m * p.tiles_n + 7) / 8 * 8;
     if (p.gn) {   // whole super-blocks, a multiple of 8 of them (one run per XCD)
         const int64_t blocks = (int64_t)((p.tiles_m + DGM_GM - 1) / DGM_GM) * p.blocks_n;
@@ -311,20 +340,42 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     int grid = 256;   // one persistent workgroup per CU; fewer when there are fewer tiles (always a multiple of 8)
     if (const char* e = std::getenv("VTD_DGM_GRID")) grid = std::max(8, std::atoi(e) / 8 * 8);
     if (nvb < grid) grid = (int)nvb;
-    int var = 0;
+    // Product placement of the LDS-DMA instructions: A pieces in the R interval, B pieces in the MM interval (template VAR = 16; bitwise
+    // identical to the all-in-MM placement VAR = 0, +3...5 % on the encoder's shapes).  VTD_DGM_VARIANT selects the measurement variants.
+    int var = 16;
     if (const char* e = std::getenv("VTD_DGM_VARIANT")) var = std::atoi(e);
-    if (var && !(flags & EPI_GELU)) {   // A/B measurements of the loop structure (never selected by the product)
-        static bool attr2 = false;
-        if (!attr2) {
-            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-            VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-            attr2 = true;
+    static bool attr2 = false;
+    if (!attr2) {
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        attr2 = true;
+    }
+    const dim3 gd((unsigned)grid), bd(512);
+    if (flags & EPI_GELU) {
+        // (the GELU epilogue is register-tight: with the DMA in its R interval it spills more and measured 5...13 % SLOWER)
+        if (var == 116) hipLaunchKernelGGL((dense_gemm_kernel<true, 16>), gd, bd, DGM_LDS, stream, p);
+        else hipLaunchKernelGGL((dense_gemm_kernel<true, 0>), gd, bd, DGM_LDS, stream, p);
+    } else {
+        switch (var) {
+            case 0: hipLaunchKernelGGL((dense_gemm_kernel<false, 0>), gd, bd, DGM_LDS, stream, p); break;
+            case 1: hipLaunchKernelGGL((dense_gemm_kernel<false, 1>), gd, bd, DGM_LDS, stream, p); break;
+            case 2: hipLaunchKernelGGL((dense_gemm_kernel<false, 2>), gd, bd, DGM_LDS, stream, p); break;
+            case 4: hipLaunchKernelGGL((dense_gemm_kernel<false, 4>), gd, bd, DGM_LDS, stream, p); break;
+            case 8: hipLaunchKernelGGL((dense_gemm_kernel<false, 8>), gd, bd, DGM_LDS, stream, p); break;
+            case 32: hipLaunchKernelGGL((dense_gemm_kernel<false, 32>), gd, bd, DGM_LDS, stream, p); break;
+            case 64: hipLaunchKernelGGL((dense_gemm_kernel<false, 64>), gd, bd, DGM_LDS, stream, p); break;
+            case 96: hipLaunchKernelGGL((dense_gemm_kernel<false, 96>), gd, bd, DGM_LDS, stream, p); break;
+            default: hipLaunchKernelGGL((dense_gemm_kernel<false, 16>), gd, bd, DGM_LDS, stream, p); break;
         }
-        if (var == 1) hipLaunchKernelGGL((dense_gemm_kernel<false, 1>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
-        else if (var == 4) hipLaunchKernelGGL((dense_gemm_kernel<false, 4>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
-        else hipLaunchKernelGGL((dense_gemm_kernel<false, 2>), dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
-    } else if (flags & EPI_GELU) hipLaunchKernelGGL(dense_gemm_kernel<true>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
-    else hipLaunchKernelGGL(dense_gemm_kernel<false>, dim3((unsigned)grid), dim3(512), DGM_LDS, stream, p);
+    }
     return -(int)hipGetLastError();
 }
