@@ -211,9 +211,21 @@ def main():
 
     turn = {"k": 0}
 
+    ahead = {}
+
     def next_batch():
         k = turn["k"] = (turn["k"] + 1) % ROTATE
-        return DeviceFrames(pinned_batches[k], stream=upload_stream) if args.upload else dev_batches[k]
+        if not args.upload:
+            return dev_batches[k]
+        # --upload: the copy of the NEXT step's batch is issued now, behind this step's (a video loop has its next batch staged while
+        # the current one is in the detector: pipeline._stage runs at push time, one batch ahead of the GPU); VTD_BENCH_UPLOAD_AHEAD=0
+        # issues each copy at the start of its own step instead
+        if os.environ.get("VTD_BENCH_UPLOAD_AHEAD", "1") == "0":
+            return DeviceFrames(pinned_batches[k], stream=upload_stream)
+        cur = ahead.pop(k, None) or DeviceFrames(pinned_batches[k], stream=upload_stream)
+        ahead.clear()
+        ahead[(k + 1) % ROTATE] = DeviceFrames(pinned_batches[(k + 1) % ROTATE], stream=upload_stream)
+        return cur
 
     def note(results):
         last["results"] = results
