@@ -198,3 +198,65 @@ def test_mixed_size_batches_come_back_in_frame_order(pipe):
     assert [r["frame_number"] for r in out] == list(range(7))
     assert [r["shape"][:2] for r in out] == sizes
     assert pipe.route_counts == {"device": 7, "reference": 0}
+
+
+def test_host_frames_enter_the_detector_one_interval_after_their_copy(pipe, monkeypatch):
+    """Host frames are staged (pinned buffer + copy on the upload stream) when pushed and enter the detector when the NEXT job is
+    pushed, so the detector never waits for its own batch's copy; every stage advances one job per push, results stay whole and in
+    order, the drain flushes a batch that never got its interval, and VTD_STAGE_AHEAD=0 restores detect-at-push.  Host logic only."""
+    from vtd_amd import engine
+
+    class _Eng:
+        max_batch = 8
+
+    class _Model:
+        def engine(self):
+            return _Eng()
+
+    class _Pinned:
+        released = []
+
+        def release(self, h):
+            self.released.append(h)
+
+    pinned = _Pinned()
+    monkeypatch.setattr(engine, "PINNED", pinned)
+    log = []
+    pipe.detector.model = _Model()
+    pipe._upload = object()
+    pipe._bind_device = lambda: None
+
+    def stage(chunk):
+        k = int(chunk[0][0, 0, 0])
+        log.append(("stage", k))
+        return list(chunk), f"pinned{k}"
+
+    def detect(batch):
+        log.append(("detect", int(batch[0][0, 0, 0])))
+        return {"batch": batch}
+
+    def recognise(job):
+        if "rec" not in job and not job.get("failed"):
+            log.append(("recognise", int(job["batch"][0][0, 0, 0])))
+            job["rec"] = True
+
+    def collect(job, info):
+        log.append(("collect", int(job["batch"][0][0, 0, 0])))
+        return [{"frame_number": n, "timestamp": t, "detections": []} for n, t in info]
+
+    pipe._stage, pipe.submit_detection, pipe._try_recognition, pipe.collect = stage, detect, recognise, collect
+    batches = [[np.full((4, 6, 3), k, np.uint8) for _ in range(2)] for k in range(5)]
+    outs = [pipe._pipeline_push(b, [(2 * k, 0.0), (2 * k + 1, 0.0)]) for k, b in enumerate(batches)]
+    assert [len(o) for o in outs] == [0, 0, 0, 2, 2]                      # batch k comes out with push k + 3
+    assert log[:3] == [("stage", 0), ("stage", 1), ("detect", 0)]         # batch 0 enters the detector behind batch 1's copy
+    assert log.index(("detect", 3)) > log.index(("stage", 4)) and log.index(("recognise", 2)) > log.index(("detect", 3))
+    rest = pipe._pipeline_drain()
+    assert [r["frame_number"] for o in outs for r in o] + [r["frame_number"] for r in rest] == list(range(10))
+    assert ("detect", 4) in log and log.index(("detect", 4)) > log.index(("collect", 1))   # the drain enqueues the batch still staged
+    assert sorted(pinned.released) == [f"pinned{k}" for k in range(5)]
+
+    log.clear()
+    monkeypatch.setenv("VTD_STAGE_AHEAD", "0")
+    outs = [pipe._pipeline_push(b, [(2 * k, 0.0), (2 * k + 1, 0.0)]) for k, b in enumerate(batches[:3])]
+    assert log[:2] == [("stage", 0), ("detect", 0)] and [len(o) for o in outs] == [0, 0, 2]
+    assert len(pipe._pipeline_drain()) == 4
