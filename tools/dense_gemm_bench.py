@@ -54,5 +54,5 @@ for name, N, K in shapes:
         err = float((out[rows].float() - ref).abs().max())
         if var == "0" and out0 is None:
             out0 = out.clone()
-        same = "" if var in ("0", "4", "32", "64", "96") else f"  bitwise == variant 0: {bool(torch.equal(out, out0))}"
+        same = "" if var in ("0", "4", "32", "64", "96") or out0 is None else f"  bitwise == variant 0: {bool(torch.equal(out, out0))}"
         print(f"{name:6s} N={N:5d} K={K:5d} order={order} variant={var}: {ms * 1e3:8.1f} us  {2 * M * N * K / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  max err {err:.3e}{same}")

@@ -7,7 +7,7 @@
 //   * 256 x 256 tile, 8 waves = 2 (M) x 4 (N), a wave owns 128 x 64 = 8 x 4 accumulator fragments (128 VGPRs);
 //   * operands arrive by LDS-DMA (global_load_lds_dwordx4) in K stages of 32 through a ring of four 32 KB stages, three stages ahead
 //     of the maths behind COUNTED s_waitcnt vmcnt -- never 0 inside the loop;
-//   * 64-byte LDS rows, 16-byte chunks XOR-swizzled by (row >> 2) & 3 on the SOURCE side (the DMA writes linearly) and on the read
+//   * 64-byte LDS rows, 16-byte chunks XOR-swizzled by dgm_key(row) on the SOURCE side (the DMA writes linearly) and on the read
 //     side, so the 16 lanes of a ds_read_b128 group hit 16 different bank quads;
 //   * a stage is two barrier intervals per wave: R (12 fragment reads of the stage + the wait that lets the NEXT stage's DMA land) and
 //     MM (issue the DMA three stages ahead, 32 MFMAs).  The two wave groups (wm = 0 / 1: the two waves of every SIMD) run ONE interval
@@ -37,6 +37,14 @@ struct DenseGemmParams {
     int nvb;                                         // virtual block ids to walk (tiles incl. the padding of the last super-block row)
 };
 constexpr int DGM_GM = 8;
+
+// Swizzle key of a 64-byte LDS row.  ds_read_b128 is served in four groups of 16 lanes that are NOT consecutive lanes
+// (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32): a group holds fragment rows 0-3 and 12-15 of
+// one K chunk fq and rows 4-11 of chunk fq ^ 1.  Four rows share a 256-byte bank row, so rows j, j + 4, j + 8, j + 12 (row >> 2 =
+// t = 0 .. 3) must land on four different chunks: {fq ^ k(0), (fq ^ 1) ^ k(1), (fq ^ 1) ^ k(2), fq ^ k(3)} distinct <=> k = (0, 3, 2, 1)
+// = -t mod 4.  The first version used k(t) = t -- right for groups of consecutive lanes, a 2-way conflict on every read for the real
+// ones (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, tools/gpu_pmc_dgm.sh).
+__device__ __forceinline__ int dgm_key(int row) { return (0 - (row >> 2)) & 3; }
 
 template <int N>
 __device__ __forceinline__ void dgm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -97,14 +105,14 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
 
     // ---- loader: wave w brings pieces w and w + 8 (16 rows x 64 bytes each) of the A tile and of the B tile of every stage.
     // Lane l of a piece lands at LDS row 16 piece + (l >> 2), physical chunk l & 3, and therefore fetches logical chunk
-    // (l & 3) ^ ((row >> 2) & 3) of that row.
+    // (l & 3) ^ dgm_key(row) of that row.
     auto make_tile = [&](int tm, int tn, DgmTile& t) {
         t.m0 = tm * DGM_BM;
         t.n0 = tn * DGM_BN;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (w + 8 * i) * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            const int chunk = (lane & 3) ^ dgm_key(row);
             int m = t.m0 + row;
             m = m < p.M ? m : p.M - 1;                       // rows past the end re-read the last row (never written)
             t.a[i] = m * p.lda + chunk * 8;
@@ -158,12 +166,12 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = wm * 128 + i * 16 + fr;
-        a_off[i] = row * 64 + ((fq ^ ((row >> 2) & 3)) << 4);
+        a_off[i] = row * 64 + ((fq ^ dgm_key(row)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = wn * 64 + j * 16 + fr;
-        b_off[j] = DGM_BM * 64 + row * 64 + ((fq ^ ((row >> 2) & 3)) << 4);
+        b_off[j] = DGM_BM * 64 + row * 64 + ((fq ^ dgm_key(row)) << 4);
     }
 
     floatx4 acc[8][4];
