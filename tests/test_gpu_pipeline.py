@@ -125,10 +125,13 @@ def test_upload_stream_batches_equal_resident_batches(pipeline):
     assert [p.collect(j) for j in jobs] == exp
 
 
-def test_process_video_pipelined_loop_matches_batch_pass(pipeline, tmp_path):
-    """process_video on a raw-frame source: batches ride the three-deep device pipeline (upload stream, detector,
-    post-process / recogniser streams) and come back in frame order with exactly the results of the one-shot batch pass."""
+@pytest.mark.parametrize("ahead", ["1", "0"])
+def test_process_video_pipelined_loop_matches_batch_pass(pipeline, tmp_path, monkeypatch, ahead):
+    """process_video on a raw-frame source: batches ride the device pipeline (upload stream, detector, post-process / recogniser
+    streams; host frames enter the detector one job after their copy was issued, VTD_STAGE_AHEAD=0: in the same push) and come back
+    in frame order with exactly the results of the one-shot batch pass."""
     from vtd_amd.engine import DeviceFrames
+    monkeypatch.setenv("VTD_STAGE_AHEAD", ahead)
     p, _, _ = pipeline
     frames = np.stack([synth.text_frame(400 + i)[0] for i in range(11)])
     path = tmp_path / "clip.npy"
