@@ -358,6 +358,7 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
         VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
@@ -369,9 +370,13 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     }
     const dim3 gd((unsigned)grid), bd(512);
     if (flags & EPI_GELU) {
-        // (the GELU epilogue is register-tight: with the DMA in its R interval it spills more and measured 5...13 % SLOWER)
+        // The GELU GEMM runs its two wave groups IN PHASE (VAR = 1).  Staggered, group 0's epilogue (128 values x ~17 VALU per lane:
+        // ~8.7 k cycles) fills one barrier interval and group 1's the next -- the other group has one 512-cycle MM to do and then
+        // waits, so a tile pays the epilogue twice; in phase both epilogues share one interval.  That is worth more than the stagger
+        // is at K = 768: 1.22 -> 1.14 ms (bitwise identical).  With the DMA in the R interval (VAR = 16) it spills more: slower.
         if (var == 116) hipLaunchKernelGGL((dense_gemm_kernel<true, 16>), gd, bd, DGM_LDS, stream, p);
-        else hipLaunchKernelGGL((dense_gemm_kernel<true, 0>), gd, bd, DGM_LDS, stream, p);
+        else if (var == 100) hipLaunchKernelGGL((dense_gemm_kernel<true, 0>), gd, bd, DGM_LDS, stream, p);
+        else hipLaunchKernelGGL((dense_gemm_kernel<true, 1>), gd, bd, DGM_LDS, stream, p);
     } else {
         switch (var) {
             case 0: hipLaunchKernelGGL((dense_gemm_kernel<false, 0>), gd, bd, DGM_LDS, stream, p); break;
