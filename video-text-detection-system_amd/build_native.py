@@ -16,7 +16,12 @@ if EXTRA and not VARIANT:
 OUT = os.path.join(OUT_DIR, f"libvtd_hip_{VARIANT}.so" if VARIANT else "libvtd_hip.so")
 OBJ_DIR = os.path.join(HERE, f"build_{VARIANT}" if VARIANT else "build")
 
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + CSRC] + EXTRA
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs.  Without it hipcc puts the accumulators of the 256-thread kernels into
+# AGPRs and shuffles them through v_accvgpr_read / write every K-step (41 copies per 16 MFMAs in conv_igemm<128,64,2,2,2>: the SQ
+# counters had that kernel at 7.5 vector instructions per MFMA) and needs 30-50 more registers; the 512-thread kernels already used
+# the VGPR form.  Same arithmetic, bit-identical outputs; the 4-wave launches run 2-6 % faster (classed head-entry border tiles 12 %).
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form",
+          "-I" + CSRC] + EXTRA
 # the post-process geometry replays float32 arithmetic in a fixed order: no fused multiply-add there
 PER_FILE = {"postprocess.hip": ["-ffp-contract=off"]}
 
@@ -34,6 +39,10 @@ def build(force=False, verbose=False):
     headers = (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +   # .inc: textually included graph code
                glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     newest_hdr = max(os.path.getmtime(h) for h in headers)
+    # a change of the compile flags rebuilds everything (the stamp sits beside the objects)
+    stamp, flags = os.path.join(OBJ_DIR, "flags.txt"), " ".join(COMMON) + " | " + repr(sorted(PER_FILE.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
@@ -47,6 +56,8 @@ def build(force=False, verbose=False):
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
+    with open(stamp, "w") as f:
+        f.write(flags)
     if procs or not os.path.exists(OUT):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT], check=True)
     if not VARIANT:
