@@ -16,7 +16,13 @@
 namespace {
 
 constexpr int AT_KB = 64;      // keys per block
-constexpr int AT_PAD = 72;     // halfs per LDS row (64 + 8: conflict-free 16-byte fragment reads)
+constexpr int AT_PADK = 80;    // halfs per LDS row of the K tile.  160 bytes: its ds_read_b128 fragment reads (row = fr, chunk = fq + 4 kk) hit 16
+                               // different bank quads in each of the hardware's lane groups ({0-3, 12-15, 20-27}, ...).  The first version used
+                               // 72 (144 bytes), conflict-free only for groups of consecutive lanes: SQ_LDS_BANK_CONFLICT was 40 % of the kernel's
+                               // LDS cycles (tools/gpu_pmc_trocr.sh).  The staging stores stay conflict-free at this pitch because odd rows
+                               // write the second 16 bytes of their 32-byte piece first (`sw` below).
+constexpr int AT_PADV = 72;    // ... of the V^T tile: it is read with ds_read_b64 (two groups of 32 lanes, 64 banks): 144 bytes spread the 16
+                               // rows of a fragment over 16 different 16-byte slots (160 would fold rows r and r + 8 onto one)
 
 // V^T[b][head][d][t] = qkv[b][t][2 C + head * 64 + d], t < T (zeros up to Tpad).  Workgroup = 64 tokens of one (b, head).
 __global__ __launch_bounds__(256) void trocr_vt_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ vt, int T, int Tpad, int C) {
@@ -55,8 +61,8 @@ __global__ __launch_bounds__(256) void trocr_vt_kernel(const half_t* __restrict_
 
 __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ vt, half_t* __restrict__ out,
                                                               int T, int Tpad, int C, float scale, int heads, int units, int qtiles) {
-    __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PAD];   // K tile, key-major
-    __shared__ __attribute__((aligned(16))) half_t vs[2][64 * AT_PAD];      // V^T tile, d-major
+    __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PADK];   // K tile, key-major
+    __shared__ __attribute__((aligned(16))) half_t vs[2][64 * AT_PADV];      // V^T tile, d-major
     // Workgroup -> (crop, head, query tile).  The query tiles of one (crop, head) read the same K and V^T rows (148 KB): they must run on
     // ONE XCD to find them in its L2.  Consecutive workgroup ids go to different XCDs, so XCD x = id % 8 takes the units x, x + 8, ...
     // and walks each unit's `qtiles` tiles back to back (PMC before: 3.0 GB read per launch at 287 crops, every tile fetching K / V^T
@@ -91,21 +97,22 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     // staging: thread -> (row 0..63, 32-byte half of... ) two 16-byte pieces per tile and thread
     const int srow = tid >> 2, scol = (tid & 3) * 16;   // row of the tile, first of 16 halfs
+    const int sw = (srow & 1) * 8;                        // K tile: odd rows handle the second half of their piece first (store bank conflicts)
     auto fetch = [&](int k0, half8* kreg, half8* vreg) {
         int key = k0 + srow;
         key = key < T ? key : T - 1;   // rows past the end: any valid row (their scores are masked)
         const half_t* ksrc = base + (int64_t)key * ld + C + scol;
-        kreg[0] = *(const half8*)ksrc;
-        kreg[1] = *(const half8*)(ksrc + 8);
+        kreg[0] = *(const half8*)(ksrc + sw);
+        kreg[1] = *(const half8*)(ksrc + (8 - sw));
         const half_t* vsrc = vbase + (int64_t)srow * Tpad + k0 + scol;   // d = srow, keys k0 + scol .. (zero padded to Tpad)
         vreg[0] = *(const half8*)vsrc;
         vreg[1] = *(const half8*)(vsrc + 8);
     };
     auto stage = [&](int buf, const half8* kreg, const half8* vreg) {
-        *(half8*)(&ks[buf][srow * AT_PAD + scol]) = kreg[0];
-        *(half8*)(&ks[buf][srow * AT_PAD + scol + 8]) = kreg[1];
-        *(half8*)(&vs[buf][srow * AT_PAD + scol]) = vreg[0];
-        *(half8*)(&vs[buf][srow * AT_PAD + scol + 8]) = vreg[1];
+        *(half8*)(&ks[buf][srow * AT_PADK + scol + sw]) = kreg[0];
+        *(half8*)(&ks[buf][srow * AT_PADK + scol + (8 - sw)]) = kreg[1];
+        *(half8*)(&vs[buf][srow * AT_PADV + scol]) = vreg[0];
+        *(half8*)(&vs[buf][srow * AT_PADV + scol + 8]) = vreg[1];
     };
     half8 kreg[2], vreg[2];
     fetch(0, kreg, vreg);
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
-                const half8 ka = *(const half8*)(&ks[buf][(kf * 16 + fr) * AT_PAD + kk * 32 + fq * 8]);
+                const half8 ka = *(const half8*)(&ks[buf][(kf * 16 + fr) * AT_PADK + kk * 32 + fq * 8]);
 #pragma unroll
                 for (int g = 0; g < 2; ++g) s[g][kf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[g][kk], s[g][kf], 0, 0, 0);
             }
@@ -174,8 +181,8 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const half4 va = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PAD + h * 32 + fq * 4]);
-                const half4 vb = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PAD + h * 32 + 16 + fq * 4]);
+                const half4 va = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PADV + h * 32 + fq * 4]);
+                const half4 vb = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PADV + h * 32 + 16 + fq * 4]);
                 const half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
                 for (int g = 0; g < 2; ++g) acc_o[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[g][h], acc_o[g][i], 0, 0, 0);
