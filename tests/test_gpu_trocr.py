@@ -298,3 +298,10 @@ def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golde
         again = eng.read_tap("encoder", len(crops))
         assert np.array_equal(again, enc_dg)
     side.synchronize()
+    # The measurement variants of dense_gemm.hip (among them knock-out variants that produce WRONG results) are not in the product
+    # library: their switch, once read by an instrumented build only, must leave the product's encoder states untouched.
+    for var in ("32", "64", "4"):
+        monkeypatch.setenv("VTD_DGM_VARIANT", var)
+        with eng.lock:
+            eng.encode_crops(dev, boxes)
+        assert np.array_equal(eng.read_tap("encoder", len(crops)), enc_dg), var

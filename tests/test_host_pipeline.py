@@ -160,12 +160,22 @@ def test_quiet_gc_hands_the_heap_back_and_respects_a_host_freeze(monkeypatch):
     with quiet_gc():
         assert gc.get_freeze_count() == 0
     monkeypatch.delenv("VTD_QUIET_GC")
+    # nested / concurrent entries: only the LAST one to leave hands the heap back
+    outer, inner = quiet_gc(), quiet_gc()
+    outer.__enter__()
+    inner.__enter__()
+    outer.__exit__(None, None, None)         # the first call to finish must not thaw the heap under the other
+    assert gc.get_freeze_count() > 0
+    inner.__exit__(None, None, None)
+    assert gc.get_freeze_count() == 0
     gc.freeze()                          # the host's own freeze (e.g. a pre-fork server)
     try:
+        before = gc.get_freeze_count()
+        junk = [[] for _ in range(5000)]     # alive at entry: a freeze of ours on top of the host's would move these in for good
         with quiet_gc():
-            assert gc.get_freeze_count() > 0
-        assert gc.get_freeze_count() > 0     # still frozen: the host's permanent generation was not handed back (the count itself
-                                             # may shrink: frozen objects are still freed by reference counting)
+            assert gc.get_freeze_count() <= before   # nothing added to the permanent generation (it may shrink: frozen objects
+        assert 0 < gc.get_freeze_count() <= before   # are still freed by reference counting) and nothing handed back either
+        del junk
     finally:
         gc.unfreeze()
 
@@ -198,6 +208,53 @@ def test_mixed_size_batches_come_back_in_frame_order(pipe):
     assert [r["frame_number"] for r in out] == list(range(7))
     assert [r["shape"][:2] for r in out] == sizes
     assert pipe.route_counts == {"device": 7, "reference": 0}
+
+
+def test_failing_first_group_of_a_mixed_batch_yields_every_frame_once(pipe):
+    """Round-3 advisor finding: with two shape groups in one pushed batch and the FIRST group's staging raising, that job retired at
+    once while it was the batch's only counted job, the batch looked complete and its frames came back twice ([0, 2, 0, 1, 2, 3],
+    all 'success').  Every frame must come back exactly once, in order, the failed group's with empty detections -- also when the
+    failing job is the last group, and when the detector enqueue (not the staging) is what fails."""
+    class _Eng:
+        max_batch = 8
+
+    class _Model:
+        def engine(self):
+            return _Eng()
+
+    def run(fail_shape, fail_in):
+        pipe.__dict__.pop("_inflight", None)
+        pipe.__dict__.pop("route_counts", None)
+        pipe.detector.model = _Model()
+        pipe._upload = object()
+        pipe._bind_device = lambda: None
+
+        def stage(chunk):
+            if fail_in == "stage" and chunk[0].shape[0] == fail_shape:
+                raise RuntimeError("staging failed")
+            return list(chunk), None
+
+        def detect(batch):
+            if fail_in == "detect" and batch[0].shape[0] == fail_shape:
+                raise RuntimeError("enqueue failed")
+            return {"batch": batch}
+
+        pipe._stage, pipe.submit_detection = stage, detect
+        pipe._try_recognition = lambda job: job.setdefault("rec", True)
+        pipe.collect = lambda job, info: [{"frame_number": n, "timestamp": t, "detections": ["box"]} for n, t in info]
+        sizes = [(4, 6), (8, 6), (4, 6), (8, 6)]                      # two shape groups: frames {0, 2} and {1, 3}
+        frames = [np.zeros((h, w, 3), np.uint8) for h, w in sizes]
+        out = pipe._pipeline_push(frames, [(i, i / 10) for i in range(4)])
+        out += pipe._pipeline_push(frames, [(i, i / 10) for i in range(4, 8)])
+        out += pipe._pipeline_drain()
+        assert [r["frame_number"] for r in out] == list(range(8)), (fail_shape, fail_in, [r["frame_number"] for r in out])
+        for r in out:
+            failed = sizes[r["frame_number"] % 4][0] == fail_shape
+            assert r["detections"] == ([] if failed else ["box"]), (fail_shape, fail_in, r)
+
+    for fail_in in ("stage", "detect"):
+        run(4, fail_in)   # the first group of every batch fails
+        run(8, fail_in)   # the last group fails
 
 
 def test_host_frames_enter_the_detector_one_interval_after_their_copy(pipe, monkeypatch):

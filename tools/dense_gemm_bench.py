@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """dense_gemm.hip alone on the GPU: the encoder pass's five GEMM shapes at a 287-crop batch, TFLOP/s per shape and tile order
-(VTD_DGM_ORDER=0 row-major runs per XCD, 1 super-blocks), against a float64 check of a few output entries."""
+(VTD_DGM_ORDER=0 row-major runs per XCD, 1 super-blocks), against a float64 check of a few output entries.
+
+The loop-structure variants (VTD_DGM_VARIANT / DGM_BENCH_VARIANTS) are compiled only into an instrumented library:
+    VTD_LIB_VARIANT=dgmexp VTD_EXTRA_HIPCC_FLAGS=-DVTD_DGM_EXPERIMENT python video-text-detection-system_amd/build_native.py
+    VTD_LIB_VARIANT=dgmexp python tools/dense_gemm_bench.py
+On the product library every "variant" is the shipped kernel (the switch is compiled out)."""
 import ctypes as C
 import os
 import sys

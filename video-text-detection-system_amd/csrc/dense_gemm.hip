@@ -19,6 +19,7 @@
 //     channels -> bias, GELU, one 16-byte store (fp16) or two (fp32) per row and channel group.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include "vtd_common.h"
 
 namespace {
@@ -94,7 +95,8 @@ __device__ __forceinline__ bool dgm_locate(const DenseGemmParams& p, int vb, int
     return true;
 }
 
-template <bool GELU, int VAR = 0>   // VAR (tools/dense_gemm_bench.py): 1 = wave groups in phase, 2 = no s_setprio, 4 = contiguous fetch (timing only),
+template <bool GELU, int VAR = 0>   // Product: <false, 16> and <true, 1>; everything else only with -DVTD_DGM_EXPERIMENT (launcher below).
+                                    // VAR (tools/dense_gemm_bench.py): 1 = wave groups in phase, 2 = no s_setprio, 4 = contiguous fetch (timing only),
                                     // 8 = all four LDS-DMA instructions of a stage in the R interval, 16 = the A pieces in R and the B pieces in MM,
                                     // 32 = no LDS-DMA after the prologue, 64 = fragments read once (both timing only, wrong results)
 __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p) {
@@ -332,8 +334,8 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
         return -2601;
     DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags, 0, 0, 0, 0};
     p.tiles_m = (int)((M + DGM_BM - 1) / DGM_BM);
-    int order = 1;
-    if (const char* e = std::getenv("VTD_DGM_ORDER")) order = std::atoi(e);   // 0: row-major runs per XCD (A/B measurements)
+    // measurement switches are read ONCE per process (never per launch); 0: row-major runs per XCD (A/B measurements)
+    static const int order = [] { const char* e = std::getenv("VTD_DGM_ORDER"); return e ? std::atoi(e) : 1; }();
     if (order) {
         for (int g = 4; g >= 1; --g)
             if (p.tiles_n % g == 0) { p.gn = g; break; }
@@ -346,34 +348,45 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     }
     p.nvb = (int)nvb;
     int grid = 256;   // one persistent workgroup per CU; fewer when there are fewer tiles (always a multiple of 8)
-    if (const char* e = std::getenv("VTD_DGM_GRID")) grid = std::max(8, std::atoi(e) / 8 * 8);
+    static const int grid_env = [] { const char* e = std::getenv("VTD_DGM_GRID"); return e ? std::max(8, std::atoi(e) / 8 * 8) : 0; }();
+    if (grid_env) grid = grid_env;
     if (nvb < grid) grid = (int)nvb;
     // Product placement of the LDS-DMA instructions: A pieces in the R interval, B pieces in the MM interval (template VAR = 16; bitwise
-    // identical to the all-in-MM placement VAR = 0, +3...5 % on the encoder's shapes).  VTD_DGM_VARIANT selects the measurement variants.
-    int var = 16;
-    if (const char* e = std::getenv("VTD_DGM_VARIANT")) var = std::atoi(e);
-    static bool attr2 = false;
-    if (!attr2) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)dense_gemm_kernel<false, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS));
-        attr2 = true;
-    }
+    // identical to the all-in-MM placement VAR = 0, +3...5 % on the encoder's shapes).  The GELU GEMM runs its two wave groups IN PHASE
+    // (VAR = 1).  Staggered, group 0's epilogue (128 values x ~17 VALU per lane: ~8.7 k cycles) fills one barrier interval and group 1's the
+    // next -- the other group has one 512-cycle MM to do and then waits, so a tile pays the epilogue twice; in phase both epilogues share
+    // one interval.  That is worth more than the stagger is at K = 768: 1.22 -> 1.14 ms (bitwise identical).
+    // The product library holds exactly these two instantiations (tests/test_abi.py checks the symbol table).  The loop-structure A/B
+    // variants and the knock-out variants that produce WRONG results exist only in an instrumented build (-DVTD_DGM_EXPERIMENT,
+    // tools/dense_gemm_bench.py), where VTD_DGM_VARIANT selects them.
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        auto set = [](const void* f) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DGM_LDS);
+            if (e != hipSuccess) attr_err = e;
+        };
+        set((const void*)dense_gemm_kernel<false, 16>);
+        set((const void*)dense_gemm_kernel<true, 1>);
+#ifdef VTD_DGM_EXPERIMENT
+        set((const void*)dense_gemm_kernel<true, 16>);
+        set((const void*)dense_gemm_kernel<false, 0>);
+        set((const void*)dense_gemm_kernel<true, 0>);
+        set((const void*)dense_gemm_kernel<false, 1>);
+        set((const void*)dense_gemm_kernel<false, 2>);
+        set((const void*)dense_gemm_kernel<false, 4>);
+        set((const void*)dense_gemm_kernel<false, 8>);
+        set((const void*)dense_gemm_kernel<false, 32>);
+        set((const void*)dense_gemm_kernel<false, 64>);
+        set((const void*)dense_gemm_kernel<false, 96>);
+#endif
+    });
+    VTD_HIP_CHECK(attr_err);
     const dim3 gd((unsigned)grid), bd(512);
+#ifdef VTD_DGM_EXPERIMENT
+    int var = 16;   // (instrumented build only: read per launch so tools/dense_gemm_bench.py can walk the variants in one process)
+    if (const char* e = std::getenv("VTD_DGM_VARIANT")) var = std::atoi(e);
     if (flags & EPI_GELU) {
-        // The GELU GEMM runs its two wave groups IN PHASE (VAR = 1).  Staggered, group 0's epilogue (128 values x ~17 VALU per lane:
-        // ~8.7 k cycles) fills one barrier interval and group 1's the next -- the other group has one 512-cycle MM to do and then
-        // waits, so a tile pays the epilogue twice; in phase both epilogues share one interval.  That is worth more than the stagger
-        // is at K = 768: 1.22 -> 1.14 ms (bitwise identical).  With the DMA in the R interval (VAR = 16) it spills more: slower.
         if (var == 116) hipLaunchKernelGGL((dense_gemm_kernel<true, 16>), gd, bd, DGM_LDS, stream, p);
         else if (var == 100) hipLaunchKernelGGL((dense_gemm_kernel<true, 0>), gd, bd, DGM_LDS, stream, p);
         else hipLaunchKernelGGL((dense_gemm_kernel<true, 1>), gd, bd, DGM_LDS, stream, p);
@@ -390,5 +403,9 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
             default: hipLaunchKernelGGL((dense_gemm_kernel<false, 16>), gd, bd, DGM_LDS, stream, p); break;
         }
     }
+#else
+    if (flags & EPI_GELU) hipLaunchKernelGGL((dense_gemm_kernel<true, 1>), gd, bd, DGM_LDS, stream, p);
+    else hipLaunchKernelGGL((dense_gemm_kernel<false, 16>), gd, bd, DGM_LDS, stream, p);
+#endif
     return -(int)hipGetLastError();
 }

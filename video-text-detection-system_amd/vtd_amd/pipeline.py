@@ -19,6 +19,7 @@ import contextlib
 import gc
 import os
 import logging
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, List, Optional, Tuple
@@ -29,25 +30,43 @@ import torch
 logger = logging.getLogger(__name__)
 
 
+_QUIET_GC_LOCK = threading.Lock()
+_QUIET_GC_DEPTH = 0   # entries of quiet_gc() that hold OUR freeze (nested or concurrent process_video calls)
+
+
 @contextlib.contextmanager
 def quiet_gc():
     """The frame loop allocates a few thousand small containers per batch (result dicts: plain, cycle-free, freed by reference
     counting), which keeps tripping CPython's cyclic collector -- and every full pass rescans the whole long-lived heap (modules,
     state dicts, staging buffers).  Measured on the bench's sustained leg: 9.6 k -> 12.4 k frames/s with the long-lived heap moved out
     of the collector's sight.  ``gc.freeze()`` (CPython >= 3.7) does exactly that for everything alive at loop entry; young objects
-    are still collected.  On exit the heap is handed back (``gc.unfreeze()``) unless the host application had frozen objects of its
-    own before.  VTD_QUIET_GC=0 switches it off."""
+    are still collected.  VTD_QUIET_GC=0 switches it off.
+
+    Process-global state, so: when the host application has frozen objects of its own (the prefork ``gc.freeze()`` pattern) this does
+    NOTHING -- the host made its choice, and a freeze of ours on top could never be undone without thawing the host's objects too
+    (every call would leave more of the heap permanently uncollectable).  Nested and concurrent entries are counted: the first one
+    freezes, only the last one to leave unfreezes (the first call to finish must not thaw the heap under the others)."""
+    global _QUIET_GC_DEPTH
     if os.environ.get("VTD_QUIET_GC", "1") == "0" or not hasattr(gc, "freeze"):
         yield
         return
-    ours = gc.get_freeze_count() == 0
-    gc.collect()
-    gc.freeze()
+    with _QUIET_GC_LOCK:
+        if _QUIET_GC_DEPTH == 0 and gc.get_freeze_count() != 0:
+            ours = False               # the host's freeze: leave the collector's state alone
+        else:
+            ours = True
+            if _QUIET_GC_DEPTH == 0:
+                gc.collect()
+                gc.freeze()
+            _QUIET_GC_DEPTH += 1
     try:
         yield
     finally:
         if ours:
-            gc.unfreeze()
+            with _QUIET_GC_LOCK:
+                _QUIET_GC_DEPTH -= 1
+                if _QUIET_GC_DEPTH == 0:
+                    gc.unfreeze()
 
 
 def _is_overridden(obj, name, owner_cls):
@@ -223,35 +242,35 @@ class VideoTextPipeline:
         cap = getattr(self.detector.model.engine(), "max_batch", len(frames))
         # results of one pushed batch are handed back together, in frame order, once its last group retires (jobs retire in
         # submission order, so batches stay in order too)
-        token = {"left": 0, "parts": []}
-        for positions in self._shape_groups(frames):
-            for start in range(0, len(positions), cap):
-                idx = positions[start:start + cap]
-                tick = self.__dict__["_tick"] = self.__dict__.get("_tick", 0) + 1
-                job = {"info": [frame_info[i] for i in idx], "host": None, "token": token, "pos": idx}
-                try:
-                    batch, job["host"] = self._stage([frames[i] for i in idx])
-                    if ahead and job["host"] is not None:
-                        job["staged"] = batch
-                    else:
-                        self._enqueue_detection(job, batch, tick)
-                except Exception as e:
-                    # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
-                    # that cannot be enqueued degrades to empty detections for its frames, the video goes on
-                    logger.error(f"Detection failed: {e}")
-                    job["failed"] = True
-                token["left"] += 1
-                self._route_count("device", len(idx))
-                self._inflight.append(job)
-                for older in self._inflight[:-1]:            # GPU work first ...
-                    if "staged" in older:                   # its copy left one interval ago
-                        self._enqueue_detection(older, older.pop("staged"), tick)
-                for older in self._inflight[:-1]:            # ... then what makes the host wait (the boxes of a batch)
-                    if "rec" not in older and not older.get("failed") and older.get("det_tick", tick) < tick:
-                        self._try_recognition(older)
-                        older["rec_tick"] = tick
-                while self._inflight and (self._inflight[0].get("failed") or self._inflight[0].get("rec_tick", tick) < tick):
-                    out += self._retire(self._inflight.pop(0))
+        # ("left" is the batch's TOTAL job count from the start: a first job that fails at once and retires while it is the only one
+        # in flight must not look like the batch's last -- its frames would be handed back twice, round-3 advisor finding)
+        jobs = [positions[start:start + cap] for positions in self._shape_groups(frames) for start in range(0, len(positions), cap)]
+        token = {"left": len(jobs), "parts": []}
+        for idx in jobs:
+            tick = self.__dict__["_tick"] = self.__dict__.get("_tick", 0) + 1
+            job = {"info": [frame_info[i] for i in idx], "host": None, "token": token, "pos": idx}
+            try:
+                batch, job["host"] = self._stage([frames[i] for i in idx])
+                if ahead and job["host"] is not None:
+                    job["staged"] = batch
+                else:
+                    self._enqueue_detection(job, batch, tick)
+            except Exception as e:
+                # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
+                # that cannot be enqueued degrades to empty detections for its frames, the video goes on
+                logger.error(f"Detection failed: {e}")
+                job["failed"] = True
+            self._route_count("device", len(idx))
+            self._inflight.append(job)
+            for older in self._inflight[:-1]:            # GPU work first ...
+                if "staged" in older:                   # its copy left one interval ago
+                    self._enqueue_detection(older, older.pop("staged"), tick)
+            for older in self._inflight[:-1]:            # ... then what makes the host wait (the boxes of a batch)
+                if "rec" not in older and not older.get("failed") and older.get("det_tick", tick) < tick:
+                    self._try_recognition(older)
+                    older["rec_tick"] = tick
+            while self._inflight and (self._inflight[0].get("failed") or self._inflight[0].get("rec_tick", tick) < tick):
+                out += self._retire(self._inflight.pop(0))
         return out
 
     def _enqueue_detection(self, job, batch, tick):
@@ -295,7 +314,8 @@ class VideoTextPipeline:
         token["left"] -= 1
         if token["left"]:
             return []
-        return [r for _, r in sorted(token["parts"], key=lambda t: t[0])]
+        parts, token["parts"] = token["parts"], []
+        return [r for _, r in sorted(parts, key=lambda t: t[0])]
 
     def _pipeline_drain(self) -> List[Dict]:
         self._bind_device()
