@@ -61,7 +61,10 @@ int vtd_detector_set_tensor(vtd_detector* d, const char* key, const float* host_
  * head conv as one algebraically composed convolution (the 256-channel P2 map is never formed; its "p2" tap is then
  * unavailable).  0 keeps the layer-by-layer graph.
  * "fuse_stem_pool" (default 1): backbone conv1 7x7/s2 + bn1 + relu + maxpool 3x3/s2 run as one kernel that only writes the
- * pooled map (tap "pool"); 0 runs the generic convolution + a separate pool kernel and exposes the tap "stem". */
+ * pooled map (tap "pool"); 0 runs the generic convolution + a separate pool kernel and exposes the tap "stem".
+ * "fuse_downsample" (default 1): the 1x1 projection + BatchNorm on the residual branch of a ResNet downsample block
+ * (text_detector.py:16-19 -> torchvision BasicBlock / Bottleneck `downsample`) is evaluated inside the block's last
+ * convolution as extra K-steps over the block input (the projected map is never written); 0 runs it as its own launch. */
 int vtd_detector_set_option(vtd_detector* d, const char* name, int value);
 /* Folds BatchNorm, repacks to the kernels' fp16 layouts and uploads.  Fails (-1103) if a key is missing. */
 int vtd_detector_finalize(vtd_detector* d, vtd_stream stream);
@@ -117,6 +120,10 @@ void vtd_recognizer_destroy(vtd_recognizer* r);
 /* One tensor of the CRNN checkpoint (text_recognizer.py:95-96): "cnn.N.*", "rnn.weight_ih_l0[_reverse]", ...,
  * "classifier.weight|bias"; float32, PyTorch memory order. */
 int vtd_recognizer_set_tensor(vtd_recognizer* r, const char* key, const float* host_data, int64_t numel);
+/* Build options, before finalize.  "fuse_pools" (default 1): the MaxPool2d((2,2)) / ((2,1)) layers behind conv2, conv4 and
+ * conv6 + ReLU (text_recognizer.py:17-22) are taken in those convolutions' epilogues (the un-pooled maps are never written;
+ * bit-identical results); 0 runs them as separate pool launches. */
+int vtd_recognizer_set_option(vtd_recognizer* r, const char* name, int value);
 int vtd_recognizer_finalize(vtd_recognizer* r, vtd_stream stream);
 /* K6: for every box (frame, x1, y1, x2, y2) take frame[y1:y2, x1:x2] (pipeliine.py:121) out of frames_dev
  * ([n_frames,H,W,3] uint8 BGR) and cv2.resize it to 128x32 (text_recognizer.py:118), then run conv1.  boxes_dev is

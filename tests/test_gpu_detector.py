@@ -275,6 +275,51 @@ def test_dbnet_r50_halo_plane_head_entry(hip, monkeypatch, cfg):
         eng.close()
 
 
+@pytest.mark.parametrize("backbone", ["resnet18", "resnet50"])
+def test_downsample_projection_folded_into_the_block_matches_the_separate_launch(hip, monkeypatch, backbone):
+    """A downsample block's 1x1 / stride-s projection (+ its BatchNorm) rides in the block's last convolution as extra K-steps of a
+    second source tensor (conv_igemm.hip DUAL; option fuse_downsample, default 1): three launches fewer on ResNet-18, four on
+    ResNet-50, and the projected maps are never written.  The residual sum is formed in the fp32 accumulators instead of adding the
+    fp16-rounded projection, so the two paths differ by that one rounding: stage outputs within 3e-3 of the tap's magnitude of each
+    other, both within the usual 1.5e-2 / 2e-2 of the fp32 oracle, probabilities within 2e-3; same algorithmic MAC count.  The folded
+    path is also run on every tile shape instantiated for it (bit-identical to one another: a tile shape never changes a K order)."""
+    from vtd_amd.engine import DetectorEngine, detector_profile
+    seed = 5 if backbone == "resnet18" else 6
+    sd = mynets.seeded_state_dict(lambda: mynets.DBNet(backbone), seed=seed)
+    n = 2 if backbone == "resnet18" else 1
+    x = torch.randn(n, 3, 640, 640, generator=torch.Generator().manual_seed(314))
+    ref = onets.dbnet_forward(x, sd, backbone, return_taps=True)
+    tol = 1.5e-2 if backbone == "resnet18" else 2e-2
+    monkeypatch.setenv("VTD_HALO_CONV", "0")
+
+    def run(fold, cfg=None):
+        if cfg is None: monkeypatch.delenv("VTD_FORCE_CONV_CFG", raising=False)
+        else: monkeypatch.setenv("VTD_FORCE_CONV_CFG", str(cfg))
+        eng = DetectorEngine(backbone, sd, max_batch=n, options={"fuse_downsample": fold})
+        try:
+            prob = eng.forward(x)["probability"].cpu().numpy()
+            taps = [eng.read_tap(t, n) for t in ("c2", "c3", "c4", "c5")]
+            return prob, taps, [r[0] for r in detector_profile(eng)], eng.macs_per_frame
+        finally:
+            eng.close()
+
+    p1, t1, names1, macs1 = run(1)
+    p0, t0, names0, macs0 = run(0)
+    assert len(names0) - len(names1) == (3 if backbone == "resnet18" else 4), (len(names0), len(names1))
+    assert macs0 == macs1
+    for i, name in enumerate(("c2", "c3", "c4", "c5")):
+        e1, e0, between = _rel(t1[i], ref["taps"][i].numpy()), _rel(t0[i], ref["taps"][i].numpy()), _rel(t1[i], t0[i])
+        print(backbone, name, "folded vs oracle", e1, "separate vs oracle", e0, "between", between)
+        assert e1 < tol and e0 < tol and between < 3e-3, (name, e1, e0, between)
+    assert float(np.abs(p1 - ref["probability"].numpy()).max()) <= 2e-3 and float(np.abs(p1 - p0).max()) <= 2e-3
+    if backbone == "resnet18":
+        for cfg in (0, 1, 2, 5, 6, 12, 13, 14):
+            pc, tc, names, _ = run(1, cfg)
+            for a, b, name in zip(tc, t1, ("c2", "c3", "c4", "c5")):
+                assert np.array_equal(a, b), (cfg, name)
+            assert np.array_equal(pc, p1), cfg
+
+
 def test_macs_accounting(r18):
     eng, _ = r18
     assert eng.macs_per_frame == pytest.approx(34.91e9, rel=0.01)  # SURVEY 8d: 69.8 GFLOP / frame

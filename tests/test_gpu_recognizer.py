@@ -221,3 +221,34 @@ def test_crnn_halo_convs_forced(hip, golden_dir, monkeypatch, mode):
     err = float(np.abs(logits - ref).max())
     print("halo-forced logit max abs err", err, "tolerance", pair / 100)
     assert err <= pair / 100
+
+
+@pytest.mark.parametrize("ncrops", [1, 7, 37, 272])
+def test_pools_fused_into_the_conv_epilogues_are_bit_identical(hip, monkeypatch, ncrops):
+    """The MaxPool2d((2,2)) behind conv2 and the MaxPool2d((2,1)) behind conv4 / conv6 (text_recognizer.py:17-22) ride in those
+    convolutions' register epilogues: GEMM rows run window-major, so a pooling window sits in neighbouring lanes of one accumulator
+    fragment and its maximum is two quad-permute DPP steps (option fuse_pools, default 1; three launches fewer, the un-pooled maps are
+    never written).  max commutes with the monotone fp16 rounding, so conv features and logits must equal the separate-pool graph's BIT
+    FOR BIT -- at crop counts that give partial tiles, on the shipped kernel selection and on every tile shape that can finish from
+    registers (forced), including the uneven 208- / 272-row tiles and the 256 x 256 one."""
+    from vtd_amd.engine import RecognizerEngine
+    sd = weights.calibrated_crnn_state_dict(11)
+    x = torch.from_numpy(np.concatenate([synth.glyph_batch(500 + i, 8) for i in range((ncrops + 7) // 8)])[:ncrops])
+    monkeypatch.setenv("VTD_HALO_CONV", "0")   # the un-fused graph on the implicit GEMM too: same K order on both sides
+
+    def run(fuse, cfg=None):
+        if cfg is None: monkeypatch.delenv("VTD_FORCE_CONV_CFG", raising=False)
+        else: monkeypatch.setenv("VTD_FORCE_CONV_CFG", str(cfg))
+        eng = RecognizerEngine(97, sd, max_crops=max(ncrops, 8), options={"fuse_pools": fuse})
+        try:
+            logits = eng.forward_logits(x).cpu().numpy()
+            return logits, eng.read_tap("cnn", ncrops)
+        finally:
+            eng.close()
+
+    want_logits, want_cnn = run(0)
+    assert float(np.abs(want_cnn).max()) > 0.1 and len({want_logits[i].tobytes() for i in range(ncrops)}) == ncrops   # the fixture looks at its input
+    for cfg in (None, 0, 1, 3, 5, 12, 13, 14, 15) if ncrops in (7, 272) else (None,):
+        logits, cnn = run(1, cfg)
+        assert np.array_equal(cnn, want_cnn), (ncrops, cfg)
+        assert np.array_equal(logits, want_logits), (ncrops, cfg)

@@ -859,7 +859,7 @@ int halo_launch(const HaloParams& p, hipStream_t stream) {
 
 // Shape test: can (and should) this convolution run on the halo kernel?  *tw_out = 16 or 32 picks the pixel-block shape.
 bool vtd_conv_halo_supported(const ConvParams& c, int* bn_out, int* tw_out) {
-    if (c.plist || c.stride != 1 || c.kw != 3 || c.K != 9 * c.in_c || (c.in_c & 63)) return false;  // 3x3, stride 1, whole chunks
+    if (c.plist || c.in2 || c.pool_pw || c.stride != 1 || c.kw != 3 || c.K != 9 * c.in_c || (c.in_c & 63)) return false;  // 3x3, stride 1, whole chunks
     if (c.cin_steps * 64 != c.in_c || c.s_step != c.in_c || c.r_step != c.in_wp * c.in_c || c.k_hi_step != 32) return false;
     if ((c.cout & 63) || c.cout != c.cout_pad || c.out_c != c.cout) return false;
     if (c.flags & ~(EPI_RELU | EPI_RESIDUAL)) return false;

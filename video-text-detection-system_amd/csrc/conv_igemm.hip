@@ -47,8 +47,14 @@ __device__ __forceinline__ void pin_loads_between_mfmas() {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
+// DUAL (plain tiles only): the K range has a second segment that gathers a 1x1 window of a SECOND tensor at (oy * in2_mul >> in2_shr,
+// ox * in2_mul >> in2_shr) -- a residual branch's 1x1 projection (ResNet downsample: stride 2 -> in2_mul = 2) or a coarser pyramid
+// level (nearest-2x up-sampling: in2_shr = 1) folded into this GEMM as extra K-steps: out = W1 * im2col(in) + W2 * in2, one launch, one
+// accumulator set, the projected tensor never written.  The walk switches sources at K-step seg1_steps by recomputing the rows' base
+// pointers in place (once per tile: no second pointer set stays live in the loop).
+template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false, bool DUAL = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p, const int tiles_n) {
+    static_assert(!(CLASSED && DUAL), "the classed op has its own second source");
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
     // Tile heights that are not a multiple of 8 * NW or of 16 * WM (208, 272: chosen so that a layer's tile count fills whole rounds
@@ -92,6 +98,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int c_log = (lane & 7) ^ (((w & 1) << 2) | (lane >> 4));  // logical K-chunk this lane fetches
     const int c_off = (c_log >> 2) * p.k_hi_step + (c_log & 3) * 8; // its element offset inside a K-step
     const int howo = p.ho * p.wo;
+    // GEMM row m -> output pixel.  Plain: raster order over (image, oy, ox).  Pooled (pool_log2 = log2 of the window size: a 2 x pool_pw
+    // max-pool follows the conv's ReLU and is taken in the epilogue): WINDOW-major -- the rows of one pooling window are consecutive, so
+    // they sit in neighbouring lanes of one accumulator fragment whatever the tile shape: m = window index * window size + (dy * pool_pw + dx)
+    auto row_pixel = [&](int m, int& img, int& oy, int& ox) {
+        if (p.pool_log2 == 0) {
+            img = m / howo;
+            const int rem = m - img * howo;
+            oy = rem / p.wo;
+            ox = rem - oy * p.wo;
+        } else {
+            const int widx = m >> p.pool_log2, sub = m & ((1 << p.pool_log2) - 1);
+            img = widx / p.pool_hqwq;
+            const int rem = widx - img * p.pool_hqwq;
+            const int qy = rem / p.pool_wq, qx = rem - qy * p.pool_wq;
+            oy = 2 * qy + (p.pool_pw == 2 ? sub >> 1 : sub);
+            ox = p.pool_pw == 2 ? 2 * qx + (sub & 1) : qx;
+        }
+    };
     const half_t* aptr[A_INST];
     const half_t* aptr2[CLASSED ? A_INST : 1];
     // classed mode: a tile is BM entries of the per-image pixel list and carries its own weight class
@@ -113,9 +137,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
             const int c_off_i = (cl_i >> 2) * p.k_hi_step + (cl_i & 3) * 8;
             int m = m0 + piece * 8 + lrow;
             m = m < p.M ? m : p.M - 1;
-            const int img = m / howo;
-            const int rem = m - img * howo;
-            const int oy = rem / p.wo, ox = rem - oy * p.wo;
+            int img, oy, ox;
+            row_pixel(m, img, oy, ox);
             aptr[i] = p.in + ((int64_t)(img * p.in_hp + oy * p.stride + p.in_y0) * p.in_wp + ox * p.stride + p.in_x0) * p.in_c + c_off_i;
         }
     }
@@ -163,6 +186,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         if (CLASSED && ks == p.seg1_steps) {  // switch the walk to the second source's 3x3 window
             kb = 0; t_c = 0; t_s = 0; second = true;
             w_cin = p.cin_steps2; w_kw = p.kw2; w_s = p.s_step2; w_r = p.r_step2;
+        }
+        if constexpr (DUAL) {
+            if (ks == p.seg1_steps) {  // every load of the first segment has been issued: re-aim the row pointers at the second tensor
+                kb = 0; t_c = 0; t_s = 0;
+                w_cin = p.cin_steps2; w_kw = p.kw2; w_s = p.s_step2; w_r = p.r_step2;
+#pragma unroll
+                for (int i = 0; i < A_INST; ++i) {
+                    int piece = i * NW + w;
+                    piece = piece < A_PIECES ? piece : A_PIECES - 1;
+                    const int cl_i = (lane & 7) ^ (((piece & 1) << 2) | (lane >> 4));
+                    const int c_off_i = (cl_i >> 2) * p.k_hi_step + (cl_i & 3) * 8;
+                    int m = m0 + piece * 8 + lrow;
+                    m = m < p.M ? m : p.M - 1;
+                    int img, oy, ox;
+                    row_pixel(m, img, oy, ox);
+                    aptr[i] = p.in2 + ((int64_t)(img * p.in2_hp + ((oy * p.in2_mul) >> p.in2_shr) + p.in2_ring) * p.in2_wp +
+                                       ((ox * p.in2_mul) >> p.in2_shr) + p.in2_ring) * p.in2_c + c_off_i;
+                }
+            }
         }
     };
     auto end_step = [&]() {  // after the last load of a K-step: advance the walk (steps are always issued in K order)
@@ -380,9 +422,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
                 int m = m0 + wm * TM + j * 16 + frow;
                 ok[j] = m < p.M && (!UNEVEN || j < FM - 1 || full_row);
                 m = ok[j] ? m : p.M - 1;
+                // pooled: the lane that holds a window's first row stores the window's maximum at the POOLED pixel (magic_* and the output
+                // tensor are those of the pooled map: vtd_launch_conv)
+                if (p.pool_log2) { ok[j] = ok[j] && (frow & ((1 << p.pool_log2) - 1)) == 0; m >>= p.pool_log2; }
+                const int e_howo = p.pool_log2 ? p.pool_hqwq : howo, e_wo = p.pool_log2 ? p.pool_wq : p.wo;
                 const int img = (int)(((uint64_t)(uint32_t)m * p.magic_howo) >> 40);
-                const int rem = m - img * howo;
-                const int oy = (int)(((uint64_t)(uint32_t)rem * p.magic_wo) >> 40), ox = rem - oy * p.wo;
+                const int rem = m - img * e_howo;
+                const int oy = (int)(((uint64_t)(uint32_t)rem * p.magic_wo) >> 40), ox = rem - oy * e_wo;
                 o_off[j] = ((int64_t)(img * p.out_hp + oy + p.out_ring) * p.out_wp + ox + p.out_ring) * p.out_c;
                 r_off[j] = ((int64_t)(img * p.res_hp + (oy >> p.res_shift) + p.res_ring) * p.res_wp + (ox >> p.res_shift) + p.res_ring) * p.cout;
             }
@@ -406,6 +452,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
                         float a0 = v0[e], a1 = v1[e];
                         if (has_res) { a0 += (float)resv[j][e]; a1 += (float)resv[j][4 + e]; }
                         if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+                        if (p.pool_log2) {
+                            // max over the window's rows = lanes frow ^ 1 (and frow ^ 2): quad-permute DPP, no LDS.  Rounding to fp16 is
+                            // monotone, so max-then-round equals the separate pool kernel's round-then-max bit for bit
+                            a0 = fmaxf(a0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a0), 0xB1, 0xf, 0xf, true)));
+                            a1 = fmaxf(a1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a1), 0xB1, 0xf, 0xf, true)));
+                            if (p.pool_log2 == 2) {
+                                a0 = fmaxf(a0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a0), 0x4E, 0xf, 0xf, true)));
+                                a1 = fmaxf(a1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a1), 0x4E, 0xf, 0xf, true)));
+                            }
+                        }
                         hv[e] = (half_t)a0;
                         hv[4 + e] = (half_t)a1;
                     }
@@ -610,7 +666,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CLASSED = false, bool DUAL = false>
 int launch_cfg(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = CLASSED ? p.M / BM : (p.M + BM - 1) / BM;  // (classed: vtd_launch_conv set M for this tile height)
     const int tiles_n = p.cout_pad / BN;
@@ -621,12 +677,18 @@ int launch_cfg(const ConvParams& p, hipStream_t stream) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED>,
+        VTD_HIP_CHECK(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED, DUAL>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, stream, p, tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, STAGES, CLASSED, DUAL>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, stream, p, tiles_n);
     return -(int)hipGetLastError();
+}
+
+// plain tile shape, with or without a second K segment (ConvParams::in2 without a pixel list)
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_plain(const ConvParams& p, hipStream_t stream) {
+    return p.in2 ? launch_cfg<BM, BN, WM, WN, STAGES, false, true>(p, stream) : launch_cfg<BM, BN, WM, WN, STAGES>(p, stream);
 }
 
 }  // namespace
@@ -666,6 +728,7 @@ static bool epi_direct_eligible(const ConvParams& p) {
 bool vtd_conv_config_valid(const ConvParams& p, int cfg) {
     if (p.flags & EPI_HEAD_FINAL) return cfg == 7;
     if (p.plist) return ((cfg == 8 || cfg == 9) || ((cfg == 10 || cfg == 11) && p.plist_b && p.tile_combo_b && p.tiles_per_img_b > 0)) && p.cout_pad % 64 == 0;
+    if (p.in2 && (cfg == 3 || cfg == 4 || cfg == 15 || cfg == 16)) return false;  // a second K segment: the tile shapes instantiated for it
     switch (cfg) {
         case 0: case 1: case 2: case 14: return p.cout_pad % 128 == 0;
         case 3: case 4: case 5: case 6: case 16: return p.cout_pad % 64 == 0;
@@ -707,36 +770,57 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
     if ((p.flags & EPI_HEAD_FINAL) && (p.cout != 256 || p.cout_pad != 256 || !p.head_w || !p.prob_out)) return -1008;
     if (p.plist && (!p.tile_combo || !p.in2 || !p.bias_tab || p.tiles_per_img <= 0 || p.M % 128 || p.seg1_steps <= 0 ||
                     p.cin_steps2 <= 0 || p.kw2 <= 0 || p.stride != 1 || (p.flags & ~EPI_RELU))) return -1009;
-    if (!p.plist && (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw)))) return -1006;
+    if (!p.plist && !p.in2 && (p.cin_steps <= 0 || p.kw <= 0 || p.K != p.cin_steps * 64 * p.kw * (p.K / (p.cin_steps * 64 * p.kw)))) return -1006;
+    if (!p.plist && p.in2) {  // second K segment: whole taps of the first window, then a 1x1 window of in2 scaled by in2_mul >> in2_shr
+        const int k1 = p.seg1_steps * 64;
+        if (p.cin_steps <= 0 || p.kw <= 0 || k1 <= 0 || k1 % (p.cin_steps * 64 * p.kw) || p.cin_steps2 <= 0 || p.kw2 != 1 ||
+            p.K != k1 + p.cin_steps2 * 64 || p.in2_c < p.cin_steps2 * 64 || p.in2_mul < 1 || p.in2_mul > 2 || p.in2_shr < 0 || p.in2_shr > 1 ||
+            p.in2_ring < 0 || p.in2_hp <= 0 || p.in2_wp <= 0)
+            return -1011;
+        // the farthest pixel the second segment touches lies inside the padded second tensor
+        if ((((p.ho - 1) * p.in2_mul) >> p.in2_shr) + p.in2_ring >= p.in2_hp || (((p.wo - 1) * p.in2_mul) >> p.in2_shr) + p.in2_ring >= p.in2_wp) return -1011;
+    }
     if (cfg < 0) cfg = vtd_conv_default_config(p);
     if (!vtd_conv_config_valid(p, cfg)) return -1007;
+    const bool pooled = p.pool_pw != 0;
+    if (pooled) {  // 2 x pool_pw max-pool behind the ReLU, taken in the register epilogue (window-major GEMM rows)
+        if ((p.pool_pw != 1 && p.pool_pw != 2) || p.plist || p.in2 || p.flags != EPI_RELU || (p.ho & 1) || p.wo % p.pool_pw || !epi_direct_eligible(p) ||
+            cfg == 7)
+            return -1012;
+        p.pool_log2 = p.pool_pw == 2 ? 2 : 1;
+        p.pool_wq = p.wo / p.pool_pw;
+        p.pool_hqwq = (p.ho / 2) * p.pool_wq;
+    } else {
+        p.pool_log2 = 0;
+    }
     {   // register epilogue: plain NHWC fp16 output with bias / residual / ReLU only, and exact magic divisions for m -> (img, oy, ox)
         const char* e = getenv("VTD_EPI_DIRECT");  // tests: 0 = the LDS epilogue everywhere (read per launch so a test can flip it)
-        const bool allow = !(e && e[0] == '0');
-        const uint64_t howo = (uint64_t)p.ho * (uint64_t)p.wo;
+        const bool allow = pooled || !(e && e[0] == '0');   // (a pooled conv has no other epilogue)
+        const uint64_t wo_e = pooled ? (uint64_t)p.pool_wq : (uint64_t)p.wo;
+        const uint64_t howo = pooled ? (uint64_t)p.pool_hqwq : (uint64_t)p.ho * (uint64_t)p.wo;
         p.epi_direct = 0;
         if (allow && epi_direct_eligible(p)) {
             p.epi_direct = 1;
-            p.magic_wo = ((1ull << 40) + p.wo - 1) / p.wo;
+            p.magic_wo = ((1ull << 40) + wo_e - 1) / wo_e;
             p.magic_howo = ((1ull << 40) + howo - 1) / howo;
         }
     }
     switch (cfg) {
-        case 0: return launch_cfg<256, 128, 4, 2, 3>(p, stream);
-        case 1: return launch_cfg<128, 128, 2, 2, 2>(p, stream);
-        case 2: return launch_cfg<128, 128, 2, 2, 3>(p, stream);
+        case 0: return launch_plain<256, 128, 4, 2, 3>(p, stream);
+        case 1: return launch_plain<128, 128, 2, 2, 2>(p, stream);
+        case 2: return launch_plain<128, 128, 2, 2, 3>(p, stream);
         case 3: return launch_cfg<256, 64, 4, 1, 2>(p, stream);
         case 4: return launch_cfg<256, 64, 4, 1, 3>(p, stream);
-        case 5: return launch_cfg<128, 64, 2, 2, 2>(p, stream);
-        case 6: return launch_cfg<128, 64, 2, 2, 3>(p, stream);
+        case 5: return launch_plain<128, 64, 2, 2, 2>(p, stream);
+        case 6: return launch_plain<128, 64, 2, 2, 3>(p, stream);
         case 7: return launch_cfg<64, 256, 1, 4, 2>(p, stream);
         case 8: return launch_cfg<128, 64, 2, 2, 2, true>(p, stream);
         case 9: return launch_cfg<128, 64, 2, 2, 3, true>(p, stream);
-        case 14: return launch_cfg<256, 128, 4, 4, 3>(p, stream);
+        case 14: return launch_plain<256, 128, 4, 4, 3>(p, stream);
         case 15: return launch_cfg<256, 256, 2, 4, 2>(p, stream);
         case 16: return launch_cfg<128, 64, 2, 2, 6>(p, stream);
-        case 12: return launch_cfg<208, 128, 2, 4, 3>(p, stream);
-        case 13: return launch_cfg<272, 128, 2, 4, 3>(p, stream);
+        case 12: return launch_plain<208, 128, 2, 4, 3>(p, stream);
+        case 13: return launch_plain<272, 128, 2, 4, 3>(p, stream);
         default: {
             // 256-row classed tiles: same images, the other cut of the pixel lists
             const int n_img = p.M / (p.tiles_per_img * 128);

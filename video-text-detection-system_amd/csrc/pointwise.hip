@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void pointwise128_kernel(const PointwisePar
 bool vtd_pointwise128_supported(const ConvParams& c) {
     // 1x1, stride 1, 128 -> 256 channels, NHWC output, optional nearest-2x upsampled residual; rows of at least one tile
     const int plain = c.flags & ~EPI_RESIDUAL;
-    return !c.plist && c.K == 128 && c.in_c == 128 && c.cout == 256 && c.out_c == 256 && c.cin_steps == 2 && c.kw == 1 && c.stride == 1 && plain == 0 &&
+    return !c.plist && !c.in2 && !c.pool_pw && c.K == 128 && c.in_c == 128 && c.cout == 256 && c.out_c == 256 && c.cin_steps == 2 && c.kw == 1 && c.stride == 1 && plain == 0 &&
            (!(c.flags & EPI_RESIDUAL) || (c.res && c.res_shift == 1)) && c.wo >= 64 && (c.ho * c.wo) % 64 == 0 && c.M % (c.ho * c.wo) == 0 &&
            (uint64_t)c.M * (uint64_t)(c.ho * c.wo) < (1ull << 40);
 }

@@ -131,6 +131,10 @@ struct ConvOp {
     int tiles_per_img = 0, seg1_steps = 0, cin_steps2 = 0, kw2 = 0, s_step2 = 0, r_step2 = 0, img_h = 0, img_w = 0;
     TensorDesc in2;
     const float* bias_tab = nullptr;
+    // second K segment of a plain conv (conv_igemm.hip DUAL): a 1x1 window of `in2` at (oy * in2_mul >> in2_shr, ox * in2_mul >> in2_shr)
+    bool dual = false;
+    int in2_mul = 1, in2_shr = 0;
+    int pool_pw = 0;   // 2 x pool_pw max-pool behind the ReLU fused into the epilogue (`out` = the pooled tensor); 0 = none
 };
 
 struct Op {
@@ -168,6 +172,12 @@ static void fill_conv_params(const ConvOp& c, int n, ConvParams& p) {
         p.seg1_steps = c.seg1_steps; p.cin_steps2 = c.cin_steps2; p.kw2 = c.kw2; p.s_step2 = c.s_step2; p.r_step2 = c.r_step2;
         p.bias_tab = c.bias_tab; p.img_h = c.img_h; p.img_w = c.img_w;
         p.M = n * c.tiles_per_img * 128;
+    }
+    p.pool_pw = c.pool_pw;
+    if (c.dual) {
+        p.in2 = c.in2.ptr; p.in2_hp = c.in2.hp; p.in2_wp = c.in2.wp; p.in2_c = c.in2.c; p.in2_ring = c.in2.ring;
+        p.in2_mul = c.in2_mul; p.in2_shr = c.in2_shr;
+        p.seg1_steps = c.seg1_steps; p.cin_steps2 = c.cin_steps2; p.kw2 = 1; p.s_step2 = 0; p.r_step2 = 0;
     }
 }
 
@@ -425,8 +435,10 @@ struct ModelBase {
 // Signature of one convolution launch slot: everything kernel choice may depend on except the batch.
 static std::string conv_signature(const ConvOp& c) {
     char buf[192];
-    std::snprintf(buf, sizeof buf, "conv|in%dx%dx%d|out%dx%d|co%d|K%d|s%d|f%x|r%d|c%d", c.in.h, c.in.w, c.in.c, c.ho, c.wo, c.cout, c.K,
-                  c.stride, (unsigned)c.flags, c.has_res ? 1 + c.res_shift : 0, c.plist ? 1 : 0);
+    int len = std::snprintf(buf, sizeof buf, "conv|in%dx%dx%d|out%dx%d|co%d|K%d|s%d|f%x|r%d|c%d", c.in.h, c.in.w, c.in.c, c.ho, c.wo, c.cout, c.K,
+                            c.stride, (unsigned)c.flags, c.has_res ? 1 + c.res_shift : 0, c.plist ? 1 : 0);
+    if (c.dual) len += std::snprintf(buf + len, sizeof buf - len, "|x%dm%ds%d", c.in2.c, c.in2_mul, c.in2_shr);  // second K segment (entries of plain convs keep their keys)
+    if (c.pool_pw) std::snprintf(buf + len, sizeof buf - len, "|p2x%d", c.pool_pw);  // max-pool fused into the epilogue
     return buf;
 }
 
@@ -528,6 +540,7 @@ struct vtd_detector : vtd::ModelBase {
     bool head_tail_kernel = true;  // dedicated persistent kernel for ConvT+BN+ReLU+ConvT+sigmoid (0: generic conv, 64x256 tile)
     bool fuse_stem_pool = true;  // conv7x7/s2 + BN + ReLU + maxpool3x3/s2 in one kernel (the 320x320x64 map is never written)
     bool fuse_fpn_head = true;  // compose FPN lateral(C2) + top-down add + P2 smooth + head conv into one classed conv
+    bool fuse_downsample = true;  // a downsample block's 1x1 projection rides in the block's last conv as extra K-steps (attach_second_segment)
     // optional per-op HIP-event timing (bench / roofline accounting)
     bool profiling = false;
     int prof_only = -1;  // >= 0: only this launch slot is bracketed with events
@@ -554,6 +567,7 @@ struct vtd_detector : vtd::ModelBase {
 struct vtd_recognizer : vtd::ModelBase {
     int vocab = 0, max_crops = 0;
     bool finalized = false;
+    bool fuse_pools = true;       // the max-pools behind conv2 / conv4 / conv6 ride in those convolutions' epilogues (0: maxpool_kernel launches)
     uint8_t* resized = nullptr;   // [D,32,128,3] K6 output
     half_t* w1 = nullptr;         // conv1 fp16 [64][32] (K = 27 padded)
     float* b1 = nullptr;          // [64]
@@ -606,9 +620,17 @@ static int upload(DeviceArena& arena, const void* host, size_t bytes, void** dev
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+// Host copy of a packed conv (build_conv with `keep`): what attach_second_segment concatenates.
+struct HostConv {
+    std::vector<half_t> w;     // [cout_pad][K]
+    std::vector<float> bias;   // [cout_pad]
+    int K = 0, cout_pad = 0;
+    bool host_only = false;    // in: do not upload (the op only exists as a second K segment of another one)
+};
+
 // Generic conv: weights [cout, cin, kh, kw]; K order (r, s, c) over the input's channel stride.
 static int build_conv(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc& out, const std::string& wkey,
-                      const Fold& f, int cin, int cout, int kh, int kw, int stride, int pad, int flags) {
+                      const Fold& f, int cin, int cout, int kh, int kw, int stride, int pad, int flags, HostConv* keep = nullptr) {
     auto w = d->get(wkey, (size_t)cout * cin * kh * kw);
     if (!w) return ERR_MISSING_KEY;
     if (in.c != cin || (cin & 63) || in.ring < pad) return ERR_GEOMETRY;
@@ -628,13 +650,47 @@ static int build_conv(ModelBase* d, ConvOp& op, const TensorDesc& in, TensorDesc
     // cin % 64 == 0: a K-step never straddles two taps
     op.cin_steps = cin / 64; op.kw = kw; op.s_step = in.c; op.r_step = in.wp * in.c; op.k_hi_step = 32;
     int rc;
-    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
-    if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    if (!keep || !keep->host_only) {
+        if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+        if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    }
+    if (keep) { keep->w = wp; keep->bias = bias; keep->K = K; keep->cout_pad = cout_pad; }
     op.in = in; op.out = out; op.K = K; op.cout = cout; op.cout_pad = cout_pad; op.stride = stride;
     op.in_y0 = in.ring - pad; op.in_x0 = in.ring - pad; op.flags = flags; op.ho = ho; op.wo = wo;
     op.macs_per_image = (int64_t)ho * wo * cout * K;
     // last tap of the last output pixel must be inside the padded input
     if ((ho - 1) * stride + op.in_y0 + kh - 1 >= in.hp || (wo - 1) * stride + op.in_x0 + kw - 1 >= in.wp) return ERR_GEOMETRY;
+    return 0;
+}
+
+// Folds a 1x1 convolution of a second tensor into `op` as extra K-steps (conv_igemm.hip DUAL):
+//     op(in) + second(in2)  =  [W_op | W_second] * [im2col(in) ; in2 at (oy * mul >> shr, ox * mul >> shr)],   bias = b_op + b_second
+// -- the residual branch's projection of a ResNet downsample block (text_detector.py:17-19 -> torchvision BasicBlock / Bottleneck
+// `downsample`: 1x1 conv stride s + BN, added before the block's last ReLU; mul = s) or a coarser pyramid level's lateral (nearest-2x
+// up-sampling = shr 1).  One launch less, and the projected map is never written or read back; the sum is formed in the fp32
+// accumulators, i.e. WITHOUT the fp16 rounding of the projected map the two-launch path has (closer to the fp32 reference).
+static int attach_second_segment(ModelBase* d, ConvOp& op, const HostConv& first, const ConvOp& sec_op, const HostConv& second,
+                                 int mul, int shr) {
+    if (first.cout_pad != second.cout_pad || first.K != op.K || second.K != sec_op.K || sec_op.kw != 1 || sec_op.K != sec_op.cin_steps * 64 ||
+        sec_op.cout != op.cout || sec_op.ho != op.ho || sec_op.wo != op.wo || (first.K & 63) || (second.K & 63))
+        return ERR_GEOMETRY;
+    if (((op.ho - 1) * mul >> shr) >= sec_op.in.h || ((op.wo - 1) * mul >> shr) >= sec_op.in.w) return ERR_GEOMETRY;
+    const int K = first.K + second.K;
+    std::vector<half_t> wp((size_t)first.cout_pad * K);
+    std::vector<float> bias(first.cout_pad);
+    for (int co = 0; co < first.cout_pad; ++co) {
+        std::memcpy(&wp[(size_t)co * K], &first.w[(size_t)co * first.K], (size_t)first.K * sizeof(half_t));
+        std::memcpy(&wp[(size_t)co * K + first.K], &second.w[(size_t)co * second.K], (size_t)second.K * sizeof(half_t));
+        bias[co] = (float)((double)first.bias[co] + (double)second.bias[co]);
+    }
+    int rc;
+    if ((rc = upload(d->arena, wp.data(), wp.size() * sizeof(half_t), (void**)&op.w))) return rc;
+    if ((rc = upload(d->arena, bias.data(), bias.size() * sizeof(float), (void**)&op.bias))) return rc;
+    op.dual = true;
+    op.in2 = sec_op.in; op.in2_mul = mul; op.in2_shr = shr;
+    op.seg1_steps = first.K / 64; op.cin_steps2 = second.K / 64;
+    op.K = K;
+    op.macs_per_image += sec_op.macs_per_image;
     return 0;
 }
 
@@ -1039,15 +1095,22 @@ static int build_detector_graph(vtd_detector* d) {
             const std::string pre = "backbone." + std::to_string(4 + st) + "." + std::to_string(b);
             const int hin = x.h, hout = hin / stride;
             TensorDesc idt = x;
-            if (stride != 1 || cin != cout) {
+            const bool project = stride != 1 || cin != cout;
+            const bool fold_ds = project && d->fuse_downsample;   // the projection becomes extra K-steps of the block's last conv
+            ConvOp ds_op;
+            HostConv ds_host;
+            if (project) {
                 TensorDesc ds;
-                if ((rc = new_tensor(hout, hout, cout, ds))) return rc;
+                if (fold_ds) ds = make_desc(B, hout, hout, cout, 1, 1);   // shape bookkeeping only: the projected map is never formed
+                else if ((rc = new_tensor(hout, hout, cout, ds))) return rc;
                 Fold f;
                 if ((rc = fold_bn(d, pre + ".downsample.1", "", cout, f))) return rc;
-                ConvOp c;
-                if ((rc = build_conv(d, c, x, ds, pre + ".downsample.0.weight", f, cin, cout, 1, 1, stride, 0, 0))) return rc;
-                push_conv(c);
-                idt = ds;
+                ds_host.host_only = fold_ds;
+                if ((rc = build_conv(d, ds_op, x, ds, pre + ".downsample.0.weight", f, cin, cout, 1, 1, stride, 0, 0, &ds_host))) return rc;
+                if (!fold_ds) {
+                    push_conv(ds_op);
+                    idt = ds;
+                }
             }
             TensorDesc y;
             if (!r50) {
@@ -1061,8 +1124,14 @@ static int build_detector_graph(vtd_detector* d) {
                 if ((rc = new_tensor(hout, hout, width, y, (fuse && st == 0 && b == counts[st] - 1) ? 2 : 1))) return rc;
                 if ((rc = fold_bn(d, pre + ".bn2", "", width, f2))) return rc;
                 ConvOp c2;
-                if ((rc = build_conv(d, c2, t1, y, pre + ".conv2.weight", f2, width, width, 3, 3, 1, 1, EPI_RELU | EPI_RESIDUAL))) return rc;
-                c2.has_res = true; c2.res = idt; c2.res_shift = 0;
+                HostConv h2;
+                h2.host_only = fold_ds;
+                if ((rc = build_conv(d, c2, t1, y, pre + ".conv2.weight", f2, width, width, 3, 3, 1, 1, fold_ds ? EPI_RELU : (EPI_RELU | EPI_RESIDUAL), &h2))) return rc;
+                if (fold_ds) {
+                    if ((rc = attach_second_segment(d, c2, h2, ds_op, ds_host, stride, 0))) return rc;
+                } else {
+                    c2.has_res = true; c2.res = idt; c2.res_shift = 0;
+                }
                 push_conv(c2);
             } else {
                 TensorDesc t1, t2;
@@ -1080,8 +1149,14 @@ static int build_detector_graph(vtd_detector* d) {
                 if ((rc = new_tensor(hout, hout, cout, y, (fuse && st == 0 && b == counts[st] - 1) ? 2 : 1))) return rc;
                 if ((rc = fold_bn(d, pre + ".bn3", "", cout, f3))) return rc;
                 ConvOp c3;
-                if ((rc = build_conv(d, c3, t2, y, pre + ".conv3.weight", f3, width, cout, 1, 1, 1, 0, EPI_RELU | EPI_RESIDUAL))) return rc;
-                c3.has_res = true; c3.res = idt; c3.res_shift = 0;
+                HostConv h3;
+                h3.host_only = fold_ds;
+                if ((rc = build_conv(d, c3, t2, y, pre + ".conv3.weight", f3, width, cout, 1, 1, 1, 0, fold_ds ? EPI_RELU : (EPI_RELU | EPI_RESIDUAL), &h3))) return rc;
+                if (fold_ds) {
+                    if ((rc = attach_second_segment(d, c3, h3, ds_op, ds_host, stride, 0))) return rc;
+                } else {
+                    c3.has_res = true; c3.res = idt; c3.res_shift = 0;
+                }
                 push_conv(c3);
             }
             x = y;
@@ -1320,6 +1395,7 @@ int vtd_detector_set_option(vtd_detector* d, const char* name, int value) {
     if (std::string(name) == "fuse_fpn_head") { d->fuse_fpn_head = value != 0; return 0; }
     if (std::string(name) == "fuse_stem_pool") { d->fuse_stem_pool = value != 0; return 0; }
     if (std::string(name) == "head_tail_kernel") { d->head_tail_kernel = value != 0; return 0; }
+    if (std::string(name) == "fuse_downsample") { d->fuse_downsample = value != 0; return 0; }
     return ERR_UNKNOWN_KEY;
 }
 
@@ -1550,17 +1626,28 @@ static int build_recognizer_graph(vtd_recognizer* r) {
     for (const Spec& sp : specs) {
         const int ho = x.h + 2 * sp.pad - sp.k + 1, wo = x.w + 2 * sp.pad - sp.k + 1;
         TensorDesc y;
-        if ((rc = new_tensor(ho, wo, sp.cout, 1, y))) return rc;
+        // MaxPool2d((2, pw)) behind the conv's ReLU (text_recognizer.py:17-22): taken in the convolution's register epilogue, the
+        // un-pooled map (71 MB behind conv2 at 272 crops) is never written; bit-identical to the separate pool (conv_igemm.hip)
+        const bool pooled = sp.ph == 2 && r->fuse_pools && !(ho & 1) && wo % sp.pw == 0;
+        if (pooled) y = make_desc(D, ho, wo, sp.cout, 1, 1);   // shape bookkeeping only
+        else if ((rc = new_tensor(ho, wo, sp.cout, 1, y))) return rc;
         Fold f;
         const std::string ck = "cnn." + std::to_string(sp.conv), bk = "cnn." + std::to_string(sp.bn);
         if ((rc = fold_bn(r, bk, ck + ".bias", sp.cout, f))) return rc;
         Op o;
         o.kind = Op::CONV;
         if ((rc = build_conv(r, o.conv, x, y, ck + ".weight", f, sp.cin, sp.cout, sp.k, sp.k, 1, sp.pad, EPI_RELU))) return rc;
+        if (pooled) {
+            TensorDesc z;
+            if ((rc = new_tensor(ho / 2, wo / sp.pw, sp.cout, 1, z))) return rc;
+            o.conv.out = z;
+            o.conv.pool_pw = sp.pw;
+            y = z;
+        }
         r->ops.push_back(o);
         r->macs += o.conv.macs_per_image;
         x = y;
-        if (sp.ph) {
+        if (sp.ph && !pooled) {
             TensorDesc z;
             if ((rc = new_tensor(x.h / sp.ph, x.w / sp.pw, x.c, 1, z))) return rc;
             Op po;
@@ -1634,6 +1721,12 @@ int vtd_recognizer_set_tensor(vtd_recognizer* r, const char* key, const float* h
     if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return 0;
     r->sd[k].assign(host_data, host_data + numel);
     return 0;
+}
+
+int vtd_recognizer_set_option(vtd_recognizer* r, const char* name, int value) {
+    if (!r || !name || r->finalized) return ERR_ARG;
+    if (std::string(name) == "fuse_pools") { r->fuse_pools = value != 0; return 0; }
+    return ERR_UNKNOWN_KEY;
 }
 
 int vtd_recognizer_finalize(vtd_recognizer* r, vtd_stream stream) {

@@ -69,6 +69,9 @@ struct ConvParams {
     void* seg_out[3];
     int seg_ldc[3];
     int epi_direct;        // set by vtd_launch_conv: epilogue straight from the accumulators (conv_igemm.hip)
+    // max-pool 2 x pool_pw (stride = window) behind the ReLU, fused into the register epilogue: pool_pw = 1 or 2 (0: none); `out` is then
+    // the POOLED tensor.  pool_log2 / pool_wq / pool_hqwq are derived by vtd_launch_conv (window size log2, pooled width, pooled pixels per image)
+    int pool_pw, pool_log2, pool_wq, pool_hqwq;
     uint64_t magic_wo, magic_howo;  // ceil(2^40 / wo), ceil(2^40 / (ho * wo)) for it
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
@@ -79,6 +82,9 @@ struct ConvParams {
     int tiles_per_img;
     const half_t* in2;       // second source (L3): gathered at (y>>1, x>>1) - 1
     int in2_hp, in2_wp, in2_c, in2_ring;
+    // ---- second K segment of a plain conv (in2 set, no pixel list; conv_igemm.hip DUAL): K-steps >= seg1_steps gather the 1x1 window of
+    // in2 at (oy * in2_mul >> in2_shr, ox * in2_mul >> in2_shr) + in2_ring, cin_steps2 K-steps of 64 channels (kw2 = 1)
+    int in2_mul, in2_shr;
     int seg1_steps;          // K-steps served by `in` (5x5 window); the rest walk `in2` (3x3 window)
     int cin_steps2, kw2, s_step2, r_step2;
     const float* bias_tab;   // [25][cout] border-class bias (y class * 5 + x class)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vtd_postproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "vtd_recognizer_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "vtd_recognizer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vtd_recognizer_destroy": (None, [C.c_void_p]),
     "vtd_recognizer_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "vtd_recognizer_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -302,7 +302,7 @@ class RecognizerEngine(_Tunable):
 
     T = 31
 
-    def __init__(self, vocab_size, state_dict, max_crops=None):
+    def __init__(self, vocab_size, state_dict, max_crops=None, options=None):
         self.lib = _native.require()
         self.vocab_size = vocab_size
         self.max_crops = max_crops or int(os.environ.get("VTD_MAX_CROPS", "512"))
@@ -311,6 +311,10 @@ class RecognizerEngine(_Tunable):
         _native.check(self.lib.vtd_recognizer_create(vocab_size, self.max_crops, C.byref(h)), "vtd_recognizer_create")
         self.handle = h
         try:
+            # VTD_RECOGNIZER_OPTIONS="fuse_pools=0": build options for A/B measurements (include/vtd.h: vtd_recognizer_set_option)
+            env_opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("VTD_RECOGNIZER_OPTIONS", "").split(",") if kv)}
+            for name, value in {**env_opts, **(options or {})}.items():
+                _native.check(self.lib.vtd_recognizer_set_option(h, name.encode(), int(value)), f"vtd_recognizer_set_option({name})")
             for key, value in state_dict.items():
                 if key.endswith("num_batches_tracked"):
                     continue
