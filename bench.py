@@ -337,7 +337,8 @@ def main():
     teng = pipe.recognizer.model.engine() if args.recognizer == "trocr" and args.workload == "full" else None
     if teng is not None and not args.no_profile:
         teng.profile()                 # drop what the warm-up left
-        teng.set_profiling(1)          # HIP events around the decoder's cross-attention launch (layer 0 of every step), on its stream
+        teng.set_profiling(3)          # HIP events around every dense-GEMM launch of the encoder pass (bit 1: the kernel with the largest share
+                                       # of the recogniser's time) and the decoder's cross-attention launch of layer 0 of every step (bit 0)
     stamps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -407,28 +408,46 @@ def main():
                 json.dump(layer_rows, f, indent=1)
 
     if teng is not None and not args.no_profile:
-        # The Transformer line is bound by its recogniser, and the recogniser's dominant launch is HBM-bound: the decoder's cross-attention
-        # reads the encoder keys / values of every live row (T tokens x D x fp16, K and V) once per layer and step.
+        # The Transformer line is bound by its recogniser.  Its dominant kernel BY SHARE OF KERNEL TIME is the encoder pass's dense GEMM
+        # (profiles/r03_trocr_pipeline_kernel_stats.csv: dense_gemm_kernel 33 % against 15.5 % for the decoder's cross-attention), an
+        # MFMA-bound launch: `roofline` is that kernel's, FLOPs executed (2 M N K per launch) / its HIP-event time on the stream it is
+        # launched on, inside the timed region.  The decoder's largest launch, the HBM-bound cross-attention (every live row's encoder keys /
+        # values read once per layer and step), is kept as a secondary record.
         ms, calls, rows = teng.profile()
+        gms, gcalls, gflops = teng.gemm_profile()
         teng.set_profiling(0)
         spec = pipe.recognizer.model.spec
+        detector_roofline = roofline
+        cross = None
         if calls:
             bytes_total = rows * spec.enc_tokens * spec.dec_hidden * 2 * 2
             achieved = bytes_total / (ms * 1e-3) / 1e9
             traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")   # its largest launch: rows stated in traffic_detail
-            detector_roofline = roofline
-            roofline = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
-                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
-                        "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
-                        "algorithmic_bytes_per_launch": int(bytes_total / calls),
-                        "note": "algorithmic bytes = live rows x encoder tokens (577) x d_model (1024) x 2 B x (K + V): every byte is read once per "
-                                "launch; rows that have emitted </s> are not read (the live list shrinks from ~272 to a handful over a batch), so "
-                                "late launches are latency-bound, not bandwidth-bound; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)",
-                        "detector_dominant_kernel": detector_roofline}
+            cross = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
+                     "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
+                     "algorithmic_bytes_per_launch": int(bytes_total / calls),
+                     "note": "algorithmic bytes = live rows x encoder tokens (577) x d_model (1024) x 2 B x (K + V): every byte is read once per "
+                             "launch; rows that have emitted </s> are not read (the live list shrinks from ~272 to a handful over a batch), so "
+                             "late launches are latency-bound, not bandwidth-bound; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)"}
             if traffic_error:
-                roofline["traffic_error"] = traffic_error
+                cross["traffic_error"] = traffic_error
                 print("bench.py: " + traffic_error, file=sys.stderr)
+        if gcalls:
+            achieved = gflops / (gms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "dense_gemm_kernel<false, 16> / <true, 1> (dense_gemm.hip): the encoder pass's dense layers and the "
+                                                   "cross-attention key / value projections",
+                        "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "launches": gcalls, "avg_launch_us": round(gms / gcalls * 1e3, 2),
+                        "executed_gflop_per_launch": round(gflops / gcalls / 1e9, 2),
+                        "note": "the Transformer recogniser's kernel with the largest share of kernel time; achieved = executed FLOPs (2 M N K, "
+                                "M = crops of the merged pass x 577 tokens) summed over every launch of the timed region / their summed HIP-event "
+                                "time on the recogniser's stream; peak = nominal dense fp16",
+                        "decoder_cross_attention": cross,
+                        "detector_dominant_kernel": detector_roofline}
+        elif cross is not None:   # (reduced architectures whose GEMMs stay on the implicit GEMM)
+            roofline = dict(cross, detector_dominant_kernel=detector_roofline)
 
     # ---- sustained leg (not `value`): the same step back to back for >= --sustain-seconds, clocks before and after
     sustained = None

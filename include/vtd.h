@@ -208,11 +208,14 @@ int vtd_trocr_encode_staged_slot(vtd_trocr* t, int slot, int ncrops, vtd_stream 
 int vtd_trocr_generate_slot(vtd_trocr* t, int slot, int ncrops, int max_length, const int32_t* forced_ids_dev, int forced_len, int32_t* ids_dev,
                             float* logits_dev, vtd_stream stream);
 int vtd_trocr_last_steps(const vtd_trocr* t);
-/* Measurement hook (bench.py roofline of the Transformer line): mode 1 brackets the cross-attention launch of decoder layer 0 of every
+/* Measurement hook (bench.py roofline of the Transformer line): mode bit 0 (value 1) brackets the cross-attention launch of decoder layer 0 of every
  * step with HIP events on the decode stream; get_profile returns their summed time, the number of launches and the summed row counts the
  * launches read (exact live-row counts), then resets.  While profiling is on, generate() waits for its own completion. */
 int vtd_trocr_set_profiling(vtd_trocr* t, int mode);
 int vtd_trocr_get_profile(vtd_trocr* t, double* total_ms, int64_t* launches, int64_t* row_launches, vtd_stream stream);
+/* Mode bit 1 (value 2, may be or-ed with 1): every dense-GEMM launch of the encoder pass (the kernel with the largest share of the
+ * Transformer recogniser's time) is bracketed with HIP events on its stream; returns summed time, launches and executed FLOPs (2 M N K). */
+int vtd_trocr_get_gemm_profile(vtd_trocr* t, double* total_ms, int64_t* launches, double* total_flops, vtd_stream stream);
 int vtd_trocr_read_tap(vtd_trocr* t, const char* name, int ncrops, float* host_out, int64_t capacity, vtd_stream stream);
 int vtd_trocr_encoder_tokens(const vtd_trocr* t);
 int vtd_trocr_logits_stride(const vtd_trocr* t);

@@ -313,11 +313,19 @@ def test_downsample_projection_folded_into_the_block_matches_the_separate_launch
         assert e1 < tol and e0 < tol and between < 3e-3, (name, e1, e0, between)
     assert float(np.abs(p1 - ref["probability"].numpy()).max()) <= 2e-3 and float(np.abs(p1 - p0).max()) <= 2e-3
     if backbone == "resnet18":
-        for cfg in (0, 1, 2, 5, 6, 12, 13, 14):
-            pc, tc, names, _ = run(1, cfg)
-            for a, b, name in zip(tc, t1, ("c2", "c3", "c4", "c5")):
-                assert np.array_equal(a, b), (cfg, name)
-            assert np.array_equal(pc, p1), cfg
+        # (two groups: a forced 128-column tile is not valid for the 64-channel layers, which then follow the table -- possibly a halo
+        # kernel with another K order --, so only shapes that leave the SAME launches to the table are comparable bit for bit)
+        for group in ((0, 1, 2, 12, 13, 14), (5, 6)):
+            base = None
+            for cfg in group:
+                pc, tc, names, _ = run(1, cfg)
+                assert float(np.abs(pc - ref["probability"].numpy()).max()) <= 2e-3, cfg
+                if base is None:
+                    base = (pc, tc)
+                    continue
+                for a, b, name in zip(tc, base[1], ("c2", "c3", "c4", "c5")):
+                    assert np.array_equal(a, b), (cfg, name)
+                assert np.array_equal(pc, base[0]), cfg
 
 
 def test_macs_accounting(r18):

@@ -88,6 +88,7 @@ SIGNATURES = {
     "vtd_trocr_last_steps": (C.c_int, [C.c_void_p]),
     "vtd_trocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vtd_trocr_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "vtd_trocr_get_gemm_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p]),
     "vtd_trocr_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vtd_trocr_encoder_tokens": (C.c_int, [C.c_void_p]),
     "vtd_trocr_logits_stride": (C.c_int, [C.c_void_p]),

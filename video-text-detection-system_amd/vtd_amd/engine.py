@@ -666,6 +666,14 @@ class TrOCREngine(_Tunable):
                       "vtd_trocr_get_profile")
         return ms.value, calls.value, rows.value
 
+    def gemm_profile(self):
+        """(total ms, launches, executed FLOPs) of the encoder pass's dense-GEMM launches bracketed since the last call (profiling mode bit 1)."""
+        ms, calls, flops = C.c_double(), C.c_int64(), C.c_double()
+        torch.cuda.synchronize()
+        _native.check(self.lib.vtd_trocr_get_gemm_profile(self.handle, C.byref(ms), C.byref(calls), C.byref(flops), _stream_ptr()),
+                      "vtd_trocr_get_gemm_profile")
+        return ms.value, calls.value, flops.value
+
     def read_tap(self, name, n):
         s = self.spec
         shape = (n, 3, s.image_size, s.image_size) if name == "pixel_values" else (n, self.tokens, s.enc_hidden)
