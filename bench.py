@@ -207,7 +207,9 @@ def main():
     last = {}
     crops_seen = {"n": 0, "batches": 0}
 
-    inflight = {"det": None, "rec": None}
+    inflight = {"det": None}
+    rec_q = []                             # jobs whose recogniser has been submitted, oldest first
+    rec_lag = pipe._recognizer_lag() if args.workload == "full" else 1
 
     turn = {"k": 0}
 
@@ -252,22 +254,21 @@ def main():
     def step_full():
         job = pipe.submit_detection(next_batch())
         keep = job["det"]["keep"]
-        ready, inflight["rec"] = inflight["rec"], None
         if inflight["det"] is not None:   # same order as VideoTextPipeline._pipeline_push: recogniser of batch i-1 first ...
-            inflight["rec"] = pipe.submit_recognition(inflight["det"])
-        if ready is not None:             # ... then the result dicts of batch i-2 (the Transformer's decode of i-2 overlaps the encoder pass of i-1)
-            note(pipe.collect(ready))
+            rec_q.append(pipe.submit_recognition(inflight["det"]))
+        # ... then the result dicts of batch i-1-lag (lag = 1 for the CRNN; the Transformer recogniser keeps more tickets in flight so
+        # that the encoder pass of the next recogniser pass runs beside the decode of the one being collected: pipeline._recognizer_lag)
+        while len(rec_q) > rec_lag:
+            note(pipe.collect(rec_q.pop(0)))
         inflight["det"] = job
         return [(keep[1][:B], keep[2][:B])]
 
     def drain_full():
-        while inflight["det"] is not None or inflight["rec"] is not None:
-            if inflight["rec"] is not None:
-                note(pipe.collect(inflight["rec"]))
-                inflight["rec"] = None
-            if inflight["det"] is not None:
-                inflight["rec"] = pipe.submit_recognition(inflight["det"])
-                inflight["det"] = None
+        if inflight["det"] is not None:
+            rec_q.append(pipe.submit_recognition(inflight["det"]))
+            inflight["det"] = None
+        while rec_q:
+            note(pipe.collect(rec_q.pop(0)))
 
     # configs[4]: the batch alternates 720p / 1080p.  It goes through the very entry process_video uses (_pipeline_push): frames are
     # grouped by shape, each group is one device pass, the groups ride the three-deep pipeline and come back in frame order.

@@ -47,6 +47,11 @@ const char* vtd_version(void);
 const char* vtd_strerror(int code);
 /* number of visible HIP devices, or a negative error */
 int vtd_device_count(void);
+/* A HIP stream whose kernels are confined to the CUs named by cu_mask (bit i of word i / 32 = CU i; hipExtStreamCreateWithCUMask).
+ * The Transformer recogniser runs its encoder pass and its greedy decode on two such streams with disjoint masks (vtd_amd/engine.py:
+ * TrOCREngine), so the next batch's encoder pass overlaps the current batch's decode.  Destroy with vtd_stream_destroy. */
+int vtd_stream_create_masked(const uint32_t* cu_mask, int words, vtd_stream* out);
+int vtd_stream_destroy(vtd_stream stream);
 
 /* ---- detector: DBNet (text_detector.py:12-86) -------------------------------------------------- */
 /* backbone: "resnet18" | "resnet50" (text_detector.py:16-20; 'resnet18' is the documented repair A2).

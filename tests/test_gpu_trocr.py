@@ -258,6 +258,54 @@ def test_queued_tickets_share_one_pass_and_equal_the_synchronous_calls(base, mon
             assert np.array_equal(g, w)
 
 
+def test_encoder_pass_beside_the_previous_decode_equals_the_synchronous_calls(base, monkeypatch):
+    """Overlap mode (default): passes of two tickets, the encoder pass of pass k+1 on a stream confined to one part of the chip while
+    the decode of pass k runs on a stream confined to the rest (vtd_stream_create_masked).  Driven the way _pipeline_push drives it --
+    `pipeline_lag` tickets in flight behind the one asked for -- every ticket's ids must equal generate_crops on its own boxes, the
+    second pass must already be encoded when the first is decoded, and an engine built with VTD_TROCR_OVERLAP=0 (back to back on the
+    caller's stream) must give the same ids."""
+    from vtd_amd.engine import DeviceFrames, TrOCREngine
+    eng, sd = base
+    assert eng.overlap and eng.pipeline_lag == 3 and eng.dec_cus + eng.enc_cus == 256, "CU-masked streams were not created on this box"
+    batches = []
+    for gi, n in enumerate((4, 6, 3, 5, 7, 2, 4)):
+        frames, boxes = _crops_in_frames([synth.glyph_crop(1100 + 10 * gi + i) for i in range(n)])
+        batches.append((DeviceFrames(frames), boxes))
+    want = [eng.generate_crops(fr, bx).numpy() for fr, bx in batches]
+    side = torch.cuda.Stream()
+    noise = torch.randn(2048, 2048, device="cuda")
+
+    def drive(engine):
+        tickets, got = [], []
+        for k, (fr, bx) in enumerate(batches):
+            with torch.cuda.stream(side):          # something else keeps the unmasked part of the machine busy
+                for _ in range(4):
+                    noise.mul_(1.0001)
+            tickets.append(engine.submit_crops(fr, bx))
+            if k >= engine.pipeline_lag:
+                first = k == engine.pipeline_lag
+                got.append(engine.finish(tickets[k - engine.pipeline_lag]).numpy())
+                if first and engine.overlap:
+                    # the first finish cut the four queued tickets into two passes and enqueued BOTH encoder passes before it decoded the first
+                    assert all(t["parts"] is not None for t in tickets[:4])
+                    assert tickets[2]["parts"][0][0] is tickets[3]["parts"][0][0] and not tickets[2]["parts"][0][0]["decoded"]
+        for t in tickets[len(got):]:
+            got.append(engine.finish(t).numpy())
+        return got
+
+    for g, w in zip(drive(eng), want):
+        assert np.array_equal(g, w)
+    side.synchronize()
+    monkeypatch.setenv("VTD_TROCR_OVERLAP", "0")
+    plain = TrOCREngine(BASE_PRINTED, sd, max_crops=16)
+    try:
+        assert not plain.overlap and plain.pipeline_lag == 1
+        for g, w in zip(drive(plain), want):
+            assert np.array_equal(g, w)
+    finally:
+        plain.close()
+
+
 def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golden_dir, monkeypatch):
     """dense_gemm.hip (256 x 256 tiles, LDS-DMA ring three stages ahead behind counted waits, two wave groups one barrier interval
     apart) forced onto every dense layer of the encoder pass it fits (VTD_DENSE_GEMM=1; by default it takes them from ~80 crops up):

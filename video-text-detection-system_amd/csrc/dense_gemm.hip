@@ -350,6 +350,18 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     int grid = 256;   // one persistent workgroup per CU; fewer when there are fewer tiles (always a multiple of 8)
     static const int grid_env = [] { const char* e = std::getenv("VTD_DGM_GRID"); return e ? std::max(8, std::atoi(e) / 8 * 8) : 0; }();
     if (grid_env) grid = grid_env;
+    else {
+        // a stream confined to part of the chip (vtd_stream_create_masked: the encoder pass beside a decode): one workgroup per CU it may
+        // use -- a 256-workgroup grid on 176 CUs would run as one full round and a 45 % round behind it
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipExtStreamGetCUMask(stream, 8, mask) == hipSuccess) {
+            int cus = 0;
+            for (uint32_t w : mask) cus += __builtin_popcount(w);
+            if (cus >= 8 && cus < 256) grid = cus / 8 * 8;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (nvb < grid) grid = (int)nvb;
     // Product placement of the LDS-DMA instructions: A pieces in the R interval, B pieces in the MM interval (template VAR = 16; bitwise
     // identical to the all-in-MM placement VAR = 0, +3...5 % on the encoder's shapes).  The GELU GEMM runs its two wave groups IN PHASE

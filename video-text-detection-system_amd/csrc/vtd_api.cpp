@@ -1362,6 +1362,25 @@ const char* vtd_strerror(int code) {
     return "unknown";
 }
 
+// A stream whose kernels run on a subset of the CUs (hipExtStreamCreateWithCUMask): the Transformer recogniser's encoder pass and its
+// decode each get one, so that the decode's thousands of small dependent launches always find free CUs beside the encoder's wide ones.
+int vtd_stream_create_masked(const uint32_t* cu_mask, int words, vtd_stream* out) {
+    if (!cu_mask || words <= 0 || words > 32 || !out) return ERR_ARG;
+    bool any = false;
+    for (int i = 0; i < words; ++i) any = any || cu_mask[i] != 0;
+    if (!any) return ERR_ARG;
+    hipStream_t s = nullptr;
+    VTD_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+    *out = (vtd_stream)s;
+    return 0;
+}
+
+int vtd_stream_destroy(vtd_stream stream) {
+    if (!stream) return ERR_ARG;
+    VTD_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 int vtd_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

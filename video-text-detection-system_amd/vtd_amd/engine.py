@@ -3,6 +3,7 @@ serve as their caller-owned device buffers.  torch is plumbing here (allocation,
 FLOP is issued by libvtd_hip.so.
 """
 import ctypes as C
+import logging
 import os
 import threading
 
@@ -10,6 +11,8 @@ import numpy as np
 import torch
 
 from . import _native
+
+logger = logging.getLogger(__name__)
 
 DEFAULT_MAX_BATCH = int(os.environ.get("VTD_MAX_BATCH", "32"))
 
@@ -447,7 +450,8 @@ class TrOCREngine(_Tunable):
         from .trocr_spec import hf4_key
         self.lib = _native.require()
         self.spec = spec
-        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~40 MB of HBM each)
+        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~75 MB of HBM each: two
+                                                                                            # encoder-output slots of 28 MB per row + workspaces)
         self.lock = threading.Lock()
         cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
                                   int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
@@ -470,10 +474,16 @@ class TrOCREngine(_Tunable):
         self.slots = int(self.lib.vtd_trocr_num_slots(h))
         self._next_slot = 0
         self._queue = []          # tickets whose crops are not staged yet (submit_crops / finish)
-        self._dec_stream = None
+        self._passes = []         # encoded passes that wait for their decode, oldest first
+        self._setup_overlap()
 
     def close(self):
         if getattr(self, "handle", None):
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self._drop_masked_streams()
             self.lib.vtd_trocr_destroy(self.handle)
             self.handle = None
 
@@ -555,19 +565,59 @@ class TrOCREngine(_Tunable):
     # ---- pipelined use: recogniser batches are decoupled from detector batches ---------------------------------------------------
     # A decode step costs about the same whether 30 or 300 rows are live (~136 dependent launches), so crops are worth collecting:
     # submit_crops only QUEUES a ticket; the GPU work starts when some ticket's result is asked for (finish) or the queue would
-    # overflow the workspace, and then every queued ticket is staged into ONE encoder pass and ONE decode.  In the three-deep video
-    # loop (submit ticket i, then finish ticket i-1) that merges tickets in pairs with no extra latency in batches.
-    def decode_stream(self, stream=None):
-        """The stream a merged pass's decode runs on: the one its encoder pass was enqueued on (back to back).  VTD_TROCR_DEC_STREAM=1
-        gives the decodes a high-priority stream of their own so that the next encoder pass runs beside them.  Measured (kernel
-        traces): side by side the decoder's ~6.7 k small dependent launches wait for CU slots behind the encoder's
-        wide ones (10 -> 50 us each) and the encoder pass doubles -- 225 ms for the pair against 165 ms back to back -- so back to
-        back is the default."""
-        if os.environ.get("VTD_TROCR_DEC_STREAM", "0") != "1":
-            return stream if stream is not None else torch.cuda.current_stream()
-        if self._dec_stream is None:
-            self._dec_stream = torch.cuda.Stream(priority=-1)
-        return self._dec_stream
+    # overflow the workspace.  Queued tickets are then cut into PASSES of `pass_tickets` tickets (VTD_TROCR_PASS_TICKETS, default 2);
+    # every pass is ONE encoder pass into an encoder-output slot and ONE decode.
+    #
+    # Overlap (default; VTD_TROCR_OVERLAP=0 for the back-to-back order): the handle has two slots, and the encoder pass of pass k+1
+    # runs BESIDE the decode of pass k -- each on a stream of its own whose kernels are confined to a disjoint part of the chip
+    # (include/vtd.h: vtd_stream_create_masked; VTD_TROCR_DEC_CUS of the 256 CUs for the decode, the rest for the encoder pass).  On
+    # plain streams this lost (round 3: the decoder's ~6.7 k small dependent launches queued for CU slots behind the encoder's wide
+    # ones, 10 -> 50 us each, and the encoder pass doubled: 225 ms for the pair against 165 ms back to back); with the chip
+    # partitioned every decode launch finds its CUs free.  For the two to overlap the host must have pass k+1 queued when it starts
+    # pass k's (host-paced) decode, i.e. a caller keeps `pipeline_lag` = 2 pass_tickets - 1 tickets in flight behind the one it asks
+    # for (VideoTextPipeline._pipeline_push and bench.py do); with fewer the passes simply run back to back as before.
+    def _setup_overlap(self):
+        self.pass_tickets = max(1, int(os.environ.get("VTD_TROCR_PASS_TICKETS", "2")))
+        self.overlap = False
+        self._enc_stream = self._dec_stream = None
+        self._masked = []
+        if os.environ.get("VTD_TROCR_OVERLAP", "1") != "0" and self.slots >= 2:
+            try:
+                total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+                dec_cus = min(max(8, int(os.environ.get("VTD_TROCR_DEC_CUS", "80"))), total - 8)
+                # every (total / dec_cus)-th CU goes to the decode: spread evenly, so both partitions have CUs on every XCD whichever
+                # way the mask's bits map onto the dies
+                dec_bits = {(i * total) // dec_cus for i in range(dec_cus)}
+                words = (total + 31) // 32
+                masks = []
+                for want in (False, True):
+                    m = (C.c_uint32 * words)()
+                    for i in range(total):
+                        if (i in dec_bits) == want:
+                            m[i // 32] |= 1 << (i % 32)
+                    masks.append(m)
+                streams = []
+                for m in masks:
+                    h = C.c_void_p()
+                    _native.check(self.lib.vtd_stream_create_masked(m, words, C.byref(h)), "vtd_stream_create_masked")
+                    self._masked.append(h)
+                    streams.append(torch.cuda.ExternalStream(h.value))
+                self._enc_stream, self._dec_stream = streams
+                self.overlap = True
+                self.dec_cus, self.enc_cus = dec_cus, total - dec_cus
+            except Exception as e:   # no CU masks on this stack: the back-to-back order
+                logger.warning(f"TrOCREngine: CU-masked streams unavailable ({e}); encoder pass and decode run back to back")
+                self._drop_masked_streams()
+        self.pipeline_lag = 2 * self.pass_tickets - 1 if self.overlap else 1
+
+    def _drop_masked_streams(self):
+        self._enc_stream = self._dec_stream = None
+        for h in getattr(self, "_masked", []):
+            try:
+                self.lib.vtd_stream_destroy(h)
+            except Exception:
+                pass
+        self._masked = []
 
     def submit_crops(self, frames, boxes):
         """Queue the crops `boxes` ([(frame, x1, y1, x2, y2), ...]) of a resident frame batch; returns a ticket for ``finish``.  Nothing
@@ -578,7 +628,8 @@ class TrOCREngine(_Tunable):
         with self.lock:
             if getattr(self, "_queue", None) is None:
                 self._queue = []
-            if sum(len(t["boxes"]) for t in self._queue) + len(b) > self.max_crops:
+            room = self.max_crops * (self.slots if self.overlap else 1)
+            if sum(len(t["boxes"]) for t in self._queue) + len(b) > room:
                 self._flush()
             self._queue.append(ticket)
             if os.environ.get("VTD_TROCR_MERGE", "1") == "0":
@@ -586,73 +637,137 @@ class TrOCREngine(_Tunable):
         return ticket
 
     def _flush(self):
-        """One encoder pass + one decode for everything queued (lock held).  Tickets larger than the workspace are cut into passes of
-        max_crops rows; every ticket ends up with a list of (host ids, event, first row, rows)."""
+        """Everything queued is cut into passes and their encoder passes are enqueued (lock held).  Back-to-back mode decodes every pass
+        at once; overlap mode leaves the decodes to ``finish`` (and runs the oldest ones only when the slots run out).  Tickets larger
+        than the workspace are cut into passes of max_crops rows; every ticket ends up with a list of (pass, spans)."""
         queue, self._queue = getattr(self, "_queue", None) or [], []
         if not queue:
             return
-        rows = [(t, i) for t in queue for i in range(len(t["boxes"]))]
+        if getattr(self, "_passes", None) is None:
+            self._passes = []
+        merge = os.environ.get("VTD_TROCR_MERGE", "1") != "0"
+        groups, k = [], (self.pass_tickets if merge else 1)
+        for i in range(0, len(queue), k):
+            groups.append(queue[i:i + k])
         parts = {id(t): [] for t in queue}
-        stream = queue[-1]["stream"]
-        for start in range(0, len(rows), self.max_crops):
-            chunk = rows[start:start + self.max_crops]
-            slot = self._next_slot
-            self._next_slot = (slot + 1) % self.slots
+        for group in groups:
+            rows = [(t, i) for t in group for i in range(len(t["boxes"]))]
+            caller = group[-1]["stream"]
+            for start in range(0, len(rows), self.max_crops):
+                chunk = rows[start:start + self.max_crops]
+                while len(self._passes) >= self.slots:       # both slots hold passes that wait for their decode: run the oldest
+                    self._decode_pass(self._passes[0])
+                slot = self._next_slot
+                self._next_slot = (slot + 1) % self.slots
+                enc = self._enc_stream if self.overlap else caller
+                if self.overlap:
+                    enc.wait_stream(caller)                  # the frames the crops come out of (detector / upload order)
+                spans = {}
+                with torch.cuda.stream(enc):
+                    # runs of consecutive rows of one ticket are staged with one processor launch each
+                    off, kk = 0, 0
+                    while kk < len(chunk):
+                        t, i0 = chunk[kk]
+                        k2 = kk
+                        while k2 < len(chunk) and chunk[k2][0] is t:
+                            k2 += 1
+                        n = k2 - kk
+                        fr = t["frames"]
+                        fr.wait_ready()
+                        bb = np.ascontiguousarray(t["boxes"][i0:i0 + n])
+                        _native.check(self.lib.vtd_trocr_stage_crops_slot(self.handle, slot, C.c_void_p(fr.tensor.data_ptr()), fr.n, fr.height, fr.width,
+                                                                          bb.ctypes.data, n, off, _stream_ptr()), "vtd_trocr_stage_crops")
+                        spans.setdefault(id(t), []).append((off, i0, n))
+                        off += n
+                        kk = k2
+                    _native.check(self.lib.vtd_trocr_encode_staged_slot(self.handle, slot, off, _stream_ptr()), "vtd_trocr_encode_staged")
+                pas = {"slot": slot, "rows": off, "caller": caller, "host": None, "event": None, "ids": None, "users": 0, "decoded": False}
+                for t in group:
+                    if id(t) in spans:
+                        parts[id(t)].append((pas, spans[id(t)]))
+                        pas["users"] += 1
+                self._passes.append(pas)
+                if not self.overlap:
+                    self._decode_pass(pas)
+        for t in queue:             # only now are the tickets marked as run: an exception above leaves them unmarked
+            t["parts"] = parts[id(t)]   # (a ticket keeps its frames until it is finished: the processor launches read them asynchronously)
+
+    def _decode_pass(self, pas):
+        """Greedy decode of one encoded pass (lock held): host-paced, returns when all but the last two steps have run."""
+        if pas["decoded"]:
+            return
+        stream = self._dec_stream if self.overlap else self.decode_stream(pas["caller"])
+        host = None
+        try:
             with torch.cuda.stream(stream):
-                # runs of consecutive rows of one ticket are staged with one processor launch each
-                off, k = 0, 0
-                while k < len(chunk):
-                    t, i0 = chunk[k]
-                    k2 = k
-                    while k2 < len(chunk) and chunk[k2][0] is t:
-                        k2 += 1
-                    n = k2 - k
-                    fr = t["frames"]
-                    fr.wait_ready()
-                    bb = np.ascontiguousarray(t["boxes"][i0:i0 + n])
-                    _native.check(self.lib.vtd_trocr_stage_crops_slot(self.handle, slot, C.c_void_p(fr.tensor.data_ptr()), fr.n, fr.height, fr.width,
-                                                                      bb.ctypes.data, n, off, _stream_ptr()), "vtd_trocr_stage_crops")
-                    t.setdefault("spans", []).append((start, off, i0, n))
-                    off += n
-                    k = k2
-                _native.check(self.lib.vtd_trocr_encode_staged_slot(self.handle, slot, off, _stream_ptr()), "vtd_trocr_encode_staged")
-            with torch.cuda.stream(self.decode_stream(stream)):
-                ids, _ = self._enqueue_generate(off, slot)
+                ids, _ = self._enqueue_generate(pas["rows"], pas["slot"])
                 host = PINNED.take(tuple(ids.shape))
                 host.copy_(ids, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-            part = {"host": host, "event": ev, "ids": ids, "users": 0}
-            for t in queue:
-                mine = [(o, i0, n) for (st, o, i0, n) in t.get("spans", []) if st == start]
-                if mine:
-                    parts[id(t)].append((part, mine))
-                    part["users"] += 1
-        for t in queue:             # only now are the tickets marked as run: an exception above leaves them unmarked
-            t.pop("spans", None)    # (a ticket keeps its frames until it is finished: the processor launches read them asynchronously)
-            t["parts"] = parts[id(t)]
+            pas.update(host=host, event=ev, ids=ids)
+        except Exception:
+            if host is not None:
+                PINNED.release(host)
+            pas["failed"] = True
+            raise
+        finally:
+            pas["decoded"] = True
+            if pas in self._passes:
+                self._passes.remove(pas)
+
+    def decode_stream(self, stream=None):
+        """Back-to-back mode: the stream a pass's decode runs on is the one its encoder pass was enqueued on.  (VTD_TROCR_DEC_STREAM=1:
+        a plain high-priority stream of its own -- the round-3 experiment that lost, kept for A/B runs.)"""
+        if os.environ.get("VTD_TROCR_DEC_STREAM", "0") != "1":
+            return stream if stream is not None else torch.cuda.current_stream()
+        if self._dec_stream is None:
+            self._dec_stream = torch.cuda.Stream(priority=-1)
+        return self._dec_stream
 
     def finish(self, ticket):
         """ids [n, max_length] int32 (cpu) of a ticket, rows in the order of its boxes.  Flushes the queue when the ticket is still in
-        it (every ticket queued by then shares the pass)."""
+        it (every ticket queued by then gets its encoder pass enqueued: the passes behind this ticket's run beside its decode).
+        Host-blocking: returns when this ticket's decode has finished."""
         with self.lock:
             if ticket["parts"] is None:
                 self._flush()
+            if ticket["parts"] is not None:
+                for pas, _ in ticket["parts"]:
+                    while not pas["decoded"]:          # passes decode in the order they were encoded
+                        self._decode_pass(self._passes[0])
         if ticket["parts"] is None:    # its pass raised half way (the exception went to whoever triggered the flush)
             raise _native.NativeError("the recogniser pass this ticket was queued for failed")
         n = len(ticket["boxes"])
         out = torch.empty((n, self.spec.max_length), dtype=torch.int32)
-        for part, spans in ticket["parts"]:
-            part["event"].synchronize()
-            for off, i0, cnt in spans:
-                out[i0:i0 + cnt] = part["host"][off:off + cnt]
-            part["users"] -= 1
-            if part["users"] == 0:
-                PINNED.release(part["host"])
-                part["ids"] = None
-        ticket["parts"] = []
-        ticket["frames"] = None
+        try:
+            for pas, spans in ticket["parts"]:
+                if pas.get("failed") or pas["event"] is None:
+                    raise _native.NativeError("the recogniser pass this ticket was queued for failed")
+                pas["event"].synchronize()
+                for off, i0, cnt in spans:
+                    out[i0:i0 + cnt] = pas["host"][off:off + cnt]
+        finally:
+            for pas, _ in ticket["parts"]:
+                pas["users"] -= 1
+                if pas["users"] == 0 and pas["host"] is not None:
+                    PINNED.release(pas["host"])
+                    pas["host"] = pas["ids"] = None
+            ticket["parts"] = []
+            ticket["frames"] = None
         return out
+
+    def discard_queue(self):
+        """Drop every ticket that has not been finished (an abandoned video): queued tickets release their frame batches, encoded
+        passes are forgotten (their slots are reused in order; the handle's events keep the GPU side consistent)."""
+        with self.lock:
+            for t in getattr(self, "_queue", None) or []:
+                t["frames"] = None
+                t["parts"] = None
+            self._queue = []
+            for pas in getattr(self, "_passes", None) or []:
+                pas["decoded"] = pas["failed"] = True
+            self._passes = []
 
     def set_profiling(self, mode):
         _native.check(self.lib.vtd_trocr_set_profiling(self.handle, int(mode)), "vtd_trocr_set_profiling")

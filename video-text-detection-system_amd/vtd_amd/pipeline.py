@@ -269,9 +269,23 @@ class VideoTextPipeline:
                 if "rec" not in older and not older.get("failed") and older.get("det_tick", tick) < tick:
                     self._try_recognition(older)
                     older["rec_tick"] = tick
-            while self._inflight and (self._inflight[0].get("failed") or self._inflight[0].get("rec_tick", tick) < tick):
+            # a job retires `lag` pushes after its recogniser was submitted: 1 for the CRNN; the Transformer recogniser asks for more
+            # (engine.TrOCREngine.pipeline_lag) so that the pass BEHIND the one being decoded is already queued and its encoder pass
+            # runs beside that decode
+            lag = self._recognizer_lag()
+            while self._inflight and (self._inflight[0].get("failed") or self._inflight[0].get("rec_tick", tick) + lag <= tick):
                 out += self._retire(self._inflight.pop(0))
         return out
+
+    def _recognizer_lag(self):
+        try:
+            if getattr(self.recognizer, "use_transformer", False) and os.environ.get("VTD_TROCR_LAG", "") != "":
+                return max(1, int(os.environ["VTD_TROCR_LAG"]))
+            if getattr(self.recognizer, "use_transformer", False):
+                return max(1, int(getattr(self.recognizer.model.engine(), "pipeline_lag", 1)))
+        except Exception:
+            pass
+        return 1
 
     def _enqueue_detection(self, job, batch, tick):
         try:
@@ -330,6 +344,11 @@ class VideoTextPipeline:
         except Exception:
             pass
         self._inflight = []
+        try:   # tickets the Transformer recogniser still holds (each keeps a whole frame batch alive) must not ride into the next video
+            if getattr(self.recognizer, "use_transformer", False):
+                self.recognizer.model.engine().discard_queue()
+        except Exception as e:
+            logger.error(f"Could not discard the recogniser's queue: {e}")
 
     # ---------------------------------------------------------------------------------- batches
     def _fast_path_ok(self, frames) -> bool:
