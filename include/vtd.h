@@ -118,6 +118,18 @@ void vtd_postproc_destroy(vtd_postproc* pp);
 int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
                      float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream);
 
+/* ---- training loss, forward only (app/ml/training/trainer.py:48-56 training_step, :66-71 validation_step, :130-142 DiceLoss) --
+ * total = nn.BCELoss()(probability, probability_map) + nn.BCELoss()(threshold, threshold_map) + DiceLoss()(probability,
+ * probability_map) over `numel` float32 elements per map (any shape; 16-byte aligned device pointers), in ONE pass that reads every
+ * element once.  out4_dev = {probability BCE, threshold BCE, dice loss, total} as float32 (the reference's scalar tensors);
+ * sums5_dev (optional) = the five float64 sums behind them (BCE numerators, sum p*t, sum p, sum t).  thresh_dev / thresh_target_dev
+ * may both be null (DiceLoss alone, or a detector run without its threshold branch): that term is then 0.  smooth = DiceLoss.smooth
+ * (1e-5).  workspace_dev: vtd_dbloss_workspace_bytes() bytes, caller-owned, one per concurrent call.  fp64 accumulation in a fixed
+ * order: bitwise repeatable.  Backward, AdamW and the plateau scheduler (trainer.py:107-128) are not part of this library yet. */
+int64_t vtd_dbloss_workspace_bytes(void);
+int vtd_dbloss_forward(const float* prob_dev, const float* thresh_dev, const float* prob_target_dev, const float* thresh_target_dev, int64_t numel,
+                       float smooth, void* workspace_dev, float* out4_dev, double* sums5_dev, vtd_stream stream);
+
 /* ---- recogniser: CRNN (app/ml/models/text_recognizer.py:12-37,114-167) --------------------------- */
 /* vocab_size = len(TextRecognizer.vocab) = 97 (text_recognizer.py:86-91); max_crops text regions per call. */
 int vtd_recognizer_create(int vocab_size, int max_crops, vtd_recognizer** out);

@@ -51,6 +51,9 @@ int vtd_launch_lstm(const half_t* xs, const half_t* whh, half_t* hout, int D, in
 int vtd_launch_ctc_greedy(const float* logits, int n, int T, int V, int ld, const int32_t* id2char, int blank, int apply_softmax,
                           int32_t* out, hipStream_t s);
 int vtd_launch_compact_rows(const float* in, float* out, int64_t rows, int V, int ld, hipStream_t s);
+int vtd_dbloss_ws_bytes();
+int vtd_launch_dbloss(const float* prob, const float* thresh, const float* prob_t, const float* thresh_t, int64_t n, float smooth, double* workspace,
+                      float* out4, double* sums5, hipStream_t stream);
 
 namespace vtd {
 
@@ -1379,6 +1382,17 @@ int vtd_stream_destroy(vtd_stream stream) {
     if (!stream) return ERR_ARG;
     VTD_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     return 0;
+}
+
+// ---- training loss, forward (app/ml/training/trainer.py:48-56 / :66-71: BCELoss + BCELoss + DiceLoss on the detector's two maps)
+int64_t vtd_dbloss_workspace_bytes(void) { return vtd_dbloss_ws_bytes(); }
+
+int vtd_dbloss_forward(const float* prob_dev, const float* thresh_dev, const float* prob_target_dev, const float* thresh_target_dev, int64_t numel,
+                       float smooth, void* workspace_dev, float* out4_dev, double* sums5_dev, vtd_stream stream) {
+    if (!prob_dev || !prob_target_dev || !workspace_dev || !out4_dev || numel <= 0) return ERR_ARG;
+    if ((thresh_dev == nullptr) != (thresh_target_dev == nullptr)) return ERR_ARG;
+    return vtd_launch_dbloss(prob_dev, thresh_dev, prob_target_dev, thresh_target_dev, numel, smooth, (double*)workspace_dev, out4_dev, sums5_dev,
+                             (hipStream_t)stream);
 }
 
 int vtd_device_count(void) {

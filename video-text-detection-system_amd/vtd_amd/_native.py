@@ -86,6 +86,9 @@ SIGNATURES = {
     "vtd_trocr_encode_staged_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vtd_trocr_generate_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vtd_trocr_last_steps": (C.c_int, [C.c_void_p]),
+    "vtd_dbloss_workspace_bytes": (C.c_int64, []),
+    "vtd_dbloss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "vtd_stream_create_masked": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_stream_destroy": (C.c_int, [C.c_void_p]),
     "vtd_trocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

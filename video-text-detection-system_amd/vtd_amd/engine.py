@@ -5,6 +5,7 @@ FLOP is issued by libvtd_hip.so.
 import ctypes as C
 import logging
 import os
+import sys
 import threading
 
 import numpy as np
@@ -440,6 +441,34 @@ def decode_records_to_text(host):
     return [("".join(map(chr, rows[i][:lens[i]])), conf[i]) for i in range(len(lens))]
 
 
+_MASKED_STREAMS = {}   # (device, total CUs, decode CUs) -> (encoder stream, decode stream): process-wide, like torch's own stream pool
+_MASKED_LOCK = threading.Lock()
+
+
+def _masked_stream_pair(lib, device, total, dec_cus):
+    """Two HIP streams with disjoint CU masks (include/vtd.h: vtd_stream_create_masked), wrapped for torch.  Every (total / dec_cus)-th CU
+    goes to the decode: spread evenly, so both partitions have CUs on every XCD whichever way the mask's bits map onto the dies.  The
+    pair is created once per process and shared by every engine on the device: torch's allocators remember the streams a block was
+    used on (a pinned buffer's free records an event on each of them), so a stream handed to torch must outlive every tensor that met
+    it -- these are never destroyed (probe: tools/cumask_probe.py, a process exits cleanly with them alive)."""
+    key = (device, total, dec_cus)
+    with _MASKED_LOCK:
+        if key not in _MASKED_STREAMS:
+            dec_bits = {(i * total) // dec_cus for i in range(dec_cus)}
+            words = (total + 31) // 32
+            streams = []
+            for want in (False, True):
+                m = (C.c_uint32 * words)()
+                for i in range(total):
+                    if (i in dec_bits) == want:
+                        m[i // 32] |= 1 << (i % 32)
+                h = C.c_void_p()
+                _native.check(lib.vtd_stream_create_masked(m, words, C.byref(h)), "vtd_stream_create_masked")
+                streams.append(torch.cuda.ExternalStream(h.value))
+            _MASKED_STREAMS[key] = tuple(streams)
+        return _MASKED_STREAMS[key]
+
+
 class TrOCREngine(_Tunable):
     """The Transformer recogniser on the GPU (include/vtd.h: vtd_trocr_*): crops of resident frames, or the
     ``pixel_values`` tensor the reference hands to ``generate``, in; greedy token ids out."""
@@ -479,11 +508,11 @@ class TrOCREngine(_Tunable):
 
     def close(self):
         if getattr(self, "handle", None):
-            try:
-                torch.cuda.synchronize()
-            except Exception:
-                pass
-            self._drop_masked_streams()
+            if not sys.is_finalizing():   # work may still be queued on the shared encoder / decode streams
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
             self.lib.vtd_trocr_destroy(self.handle)
             self.handle = None
 
@@ -580,44 +609,17 @@ class TrOCREngine(_Tunable):
         self.pass_tickets = max(1, int(os.environ.get("VTD_TROCR_PASS_TICKETS", "2")))
         self.overlap = False
         self._enc_stream = self._dec_stream = None
-        self._masked = []
         if os.environ.get("VTD_TROCR_OVERLAP", "1") != "0" and self.slots >= 2:
             try:
                 total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
                 dec_cus = min(max(8, int(os.environ.get("VTD_TROCR_DEC_CUS", "80"))), total - 8)
-                # every (total / dec_cus)-th CU goes to the decode: spread evenly, so both partitions have CUs on every XCD whichever
-                # way the mask's bits map onto the dies
-                dec_bits = {(i * total) // dec_cus for i in range(dec_cus)}
-                words = (total + 31) // 32
-                masks = []
-                for want in (False, True):
-                    m = (C.c_uint32 * words)()
-                    for i in range(total):
-                        if (i in dec_bits) == want:
-                            m[i // 32] |= 1 << (i % 32)
-                    masks.append(m)
-                streams = []
-                for m in masks:
-                    h = C.c_void_p()
-                    _native.check(self.lib.vtd_stream_create_masked(m, words, C.byref(h)), "vtd_stream_create_masked")
-                    self._masked.append(h)
-                    streams.append(torch.cuda.ExternalStream(h.value))
-                self._enc_stream, self._dec_stream = streams
+                self._enc_stream, self._dec_stream = _masked_stream_pair(self.lib, torch.cuda.current_device(), total, dec_cus)
                 self.overlap = True
                 self.dec_cus, self.enc_cus = dec_cus, total - dec_cus
             except Exception as e:   # no CU masks on this stack: the back-to-back order
                 logger.warning(f"TrOCREngine: CU-masked streams unavailable ({e}); encoder pass and decode run back to back")
-                self._drop_masked_streams()
+                self._enc_stream = self._dec_stream = None
         self.pipeline_lag = 2 * self.pass_tickets - 1 if self.overlap else 1
-
-    def _drop_masked_streams(self):
-        self._enc_stream = self._dec_stream = None
-        for h in getattr(self, "_masked", []):
-            try:
-                self.lib.vtd_stream_destroy(h)
-            except Exception:
-                pass
-        self._masked = []
 
     def submit_crops(self, frames, boxes):
         """Queue the crops `boxes` ([(frame, x1, y1, x2, y2), ...]) of a resident frame batch; returns a ticket for ``finish``.  Nothing
