@@ -358,8 +358,18 @@ def main():
         elapsed = float(t.item())
     crops_per_step = crops_seen["n"] / max(crops_seen["batches"], 1)
 
-    # ---- sanity: the timed path produced detections (not part of the timed region)
+    # ---- sanity: the timed path produced detections (not part of the timed region), and nothing was swallowed on the way: the product keeps
+    # the reference's error convention (log, empty result, go on), under which a recogniser that fails every pass would post a splendid rate
     n_det = int(sum(int(cnt.sum().item()) for _, cnt in blocks))
+    swallowed = dict(getattr(pipe, "error_counts", {}) or {})
+    if swallowed:
+        print(f"bench.py: the pipeline swallowed errors during the run ({swallowed}); no number is reported", file=sys.stderr)
+        raise SystemExit(3)
+    if args.workload == "full" and last.get("results") is not None:
+        texts = [d.get("text", "") for r in last["results"] for d in r["detections"]]
+        if texts and not any(texts):
+            print("bench.py: every recognised text of the last batch is empty; no number is reported", file=sys.stderr)
+            raise SystemExit(3)
 
     roofline = None
     layer_rows = []

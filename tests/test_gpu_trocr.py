@@ -259,14 +259,14 @@ def test_queued_tickets_share_one_pass_and_equal_the_synchronous_calls(base, mon
 
 
 def test_encoder_pass_beside_the_previous_decode_equals_the_synchronous_calls(base, monkeypatch):
-    """Overlap mode (default): passes of two tickets, the encoder pass of pass k+1 on a stream confined to one part of the chip while
-    the decode of pass k runs on a stream confined to the rest (vtd_stream_create_masked).  Driven the way _pipeline_push drives it --
-    `pipeline_lag` tickets in flight behind the one asked for -- every ticket's ids must equal generate_crops on its own boxes, the
-    second pass must already be encoded when the first is decoded, and an engine built with VTD_TROCR_OVERLAP=0 (back to back on the
-    caller's stream) must give the same ids."""
+    """Overlap mode (VTD_TROCR_OVERLAP=1; measured slower than back to back, kept as an option): passes of two tickets, the encoder pass
+    of pass k+1 on a stream confined to one part of every die while the decode of pass k runs on a stream confined to the rest
+    (vtd_stream_create_masked).  Driven the way _pipeline_push drives it -- `pipeline_lag` tickets in flight behind the one asked for --
+    every ticket's ids must equal generate_crops on its own boxes, the second pass must already be encoded when the first is decoded,
+    and the default engine (back to back on the caller's stream; also with passes of four tickets) must give the same ids."""
     from vtd_amd.engine import DeviceFrames, TrOCREngine
     eng, sd = base
-    assert eng.overlap and eng.pipeline_lag == 3 and eng.dec_cus + eng.enc_cus == 256, "CU-masked streams were not created on this box"
+    assert not eng.overlap and eng.pipeline_lag == 1
     batches = []
     for gi, n in enumerate((4, 6, 3, 5, 7, 2, 4)):
         frames, boxes = _crops_in_frames([synth.glyph_crop(1100 + 10 * gi + i) for i in range(n)])
@@ -295,15 +295,43 @@ def test_encoder_pass_beside_the_previous_decode_equals_the_synchronous_calls(ba
 
     for g, w in zip(drive(eng), want):
         assert np.array_equal(g, w)
+    for env in ({"VTD_TROCR_OVERLAP": "1", "VTD_TROCR_DEC_CUS": "96"}, {"VTD_TROCR_PASS_TICKETS": "4"}):
+        for k in ("VTD_TROCR_OVERLAP", "VTD_TROCR_DEC_CUS", "VTD_TROCR_PASS_TICKETS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = TrOCREngine(BASE_PRINTED, sd, max_crops=32)
+        try:
+            if "VTD_TROCR_OVERLAP" in env:
+                assert other.overlap and other.pipeline_lag == 3 and other.dec_cus == 96 and other.enc_cus == 160, "CU-masked streams were not created on this box"
+            else:
+                assert not other.overlap and other.pipeline_lag == 3
+            for g, w in zip(drive(other), want):
+                assert np.array_equal(g, w)
+        finally:
+            other.close()
     side.synchronize()
-    monkeypatch.setenv("VTD_TROCR_OVERLAP", "0")
-    plain = TrOCREngine(BASE_PRINTED, sd, max_crops=16)
+
+
+def test_pass_taller_than_the_dense_gemms_32_bit_offsets_runs_as_row_blocks(base):
+    """dense_gemm.hip addresses its A operand with 32-bit element offsets: at the 3072-wide fc2 input that is 699 k rows = 1211 crops.  A
+    recogniser pass of 1300 crops (five tickets' worth; bench.py with VTD_TROCR_PASS_TICKETS >= 5 gets there) must run -- as row blocks
+    -- and give every crop the ids it gets in a small pass, instead of failing validation and being swallowed as empty strings (what a
+    first 6-ticket run did, at a splendid 662 frames/s)."""
+    from vtd_amd.engine import DeviceFrames, TrOCREngine
+    eng, sd = base
+    crops = [synth.glyph_crop(1300 + i) for i in range(8)]
+    frames, boxes = _crops_in_frames(crops)
+    dev = DeviceFrames(frames)
+    want = eng.generate_crops(dev, boxes).numpy()
+    big = TrOCREngine(BASE_PRINTED, sd, max_crops=1304)
     try:
-        assert not plain.overlap and plain.pipeline_lag == 1
-        for g, w in zip(drive(plain), want):
-            assert np.array_equal(g, w)
+        many = [boxes[i % 8] for i in range(1300)]
+        got = big.generate_crops(dev, many).numpy()
     finally:
-        plain.close()
+        big.close()
+    for i in range(1300):
+        assert np.array_equal(got[i], want[i % 8]), i
 
 
 def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golden_dir, monkeypatch):

@@ -329,9 +329,23 @@ bool vtd_dense_gemm_supported(int64_t M, int N, int K, int lda, int ldc, int fla
 int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows, const float* bias, void* out, int ldc, int64_t M, int N, int K,
                           int flags, hipStream_t stream) {
     if (M < 256 || N < 256 || (N & 7) || (K & 31) || K < 128 || (lda & 7) || (ldc & 7) || M > 0x7fffffff ||
-        !(flags & (EPI_OUT_F16 | EPI_OUT_F32)) || (flags & ~(EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU)) ||
-        M * (int64_t)lda >= 0x7fffffff || (int64_t)w_rows * K >= 0x7fffffff)
+        !(flags & (EPI_OUT_F16 | EPI_OUT_F32)) || (flags & ~(EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU)) || (int64_t)w_rows * K >= 0x7fffffff)
         return -2601;
+    if (M * (int64_t)lda >= 0x7fffffff) {
+        // the kernel addresses A with 32-bit element offsets: a taller operand (a recogniser pass of > ~1200 crops at the 3072-wide fc2
+        // input) runs as row blocks, each a launch of its own on the same stream -- every output row is computed exactly as before
+        const int64_t rows = ((int64_t)0x7ffffffe / lda) / DGM_BM * DGM_BM;
+        if (rows < DGM_BM) return -2601;
+        const size_t esz = (flags & EPI_OUT_F16) ? sizeof(half_t) : sizeof(float);
+        for (int64_t m0 = 0; m0 < M; m0 += rows) {
+            const int64_t mb = std::min(rows, M - m0);
+            int rc;
+            if (mb >= 256) rc = vtd_launch_dense_gemm(A + m0 * lda, lda, W, w_rows, bias, (char*)out + (size_t)m0 * ldc * esz, ldc, mb, N, K, flags, stream);
+            else rc = vtd_launch_dense_gemm(A + (M - 256) * lda, lda, W, w_rows, bias, (char*)out + (size_t)(M - 256) * ldc * esz, ldc, 256, N, K, flags, stream);  // a short tail: the last 256 rows again (same values)
+            if (rc) return rc;
+        }
+        return 0;
+    }
     DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags, 0, 0, 0, 0};
     p.tiles_m = (int)((M + DGM_BM - 1) / DGM_BM);
     // measurement switches are read ONCE per process (never per launch); 0: row-major runs per XCD (A/B measurements)

@@ -446,27 +446,38 @@ _MASKED_LOCK = threading.Lock()
 
 
 def _masked_stream_pair(lib, device, total, dec_cus):
-    """Two HIP streams with disjoint CU masks (include/vtd.h: vtd_stream_create_masked), wrapped for torch.  Every (total / dec_cus)-th CU
-    goes to the decode: spread evenly, so both partitions have CUs on every XCD whichever way the mask's bits map onto the dies.  The
-    pair is created once per process and shared by every engine on the device: torch's allocators remember the streams a block was
-    used on (a pinned buffer's free records an event on each of them), so a stream handed to torch must outlive every tensor that met
-    it -- these are never destroyed (probe: tools/cumask_probe.py, a process exits cleanly with them alive)."""
-    key = (device, total, dec_cus)
+    """Two HIP streams with disjoint CU masks (include/vtd.h: vtd_stream_create_masked), wrapped for torch.
+
+    What a mask bit means on this part was measured, not assumed (tools/cumask_map.py on an MI355X, ROCm 7.2): bit i enables CU
+    i // 8 of XCC (die) i % 8, and a die whose bits are ALL zero is not masked at all -- every one of its CUs stays enabled.  So a
+    partition must leave every die some CUs on both sides: the decode gets CUs 0 .. dec_cus / 8 - 1 of every die, the encoder pass the
+    other ones (an evenly 'strided' mask, the first thing tried, emptied whole dies on one side and partitioned nothing).  Equal
+    shares per die also keep the persistent dense GEMM's one-workgroup-per-CU grid balanced (dense_gemm.hip sizes its grid by the
+    stream's mask).  The pair is created once per process and shared by every engine on the device: torch's allocators remember the
+    streams a block was used on (a pinned buffer's free records an event on each of them), so a stream handed to torch must outlive
+    every tensor that met it -- these are never destroyed (tools/cumask_probe.py: a process exits cleanly with them alive)."""
+    dies = 8
+    if total % dies:
+        raise _native.NativeError(f"{total} CUs do not split over {dies} dies")
+    per_die = total // dies
+    dc = min(max(1, dec_cus // dies), per_die - 1)
+    key = (device, total, dc)
     with _MASKED_LOCK:
         if key not in _MASKED_STREAMS:
-            dec_bits = {(i * total) // dec_cus for i in range(dec_cus)}
             words = (total + 31) // 32
             streams = []
-            for want in (False, True):
+            for want_dec in (False, True):
                 m = (C.c_uint32 * words)()
-                for i in range(total):
-                    if (i in dec_bits) == want:
-                        m[i // 32] |= 1 << (i % 32)
+                for die in range(dies):
+                    for cu in range(per_die):
+                        if (cu < dc) == want_dec:
+                            bit = cu * dies + die
+                            m[bit // 32] |= 1 << (bit % 32)
                 h = C.c_void_p()
                 _native.check(lib.vtd_stream_create_masked(m, words, C.byref(h)), "vtd_stream_create_masked")
                 streams.append(torch.cuda.ExternalStream(h.value))
             _MASKED_STREAMS[key] = tuple(streams)
-        return _MASKED_STREAMS[key]
+        return _MASKED_STREAMS[key] + (dc * dies,)
 
 
 class TrOCREngine(_Tunable):
@@ -597,29 +608,32 @@ class TrOCREngine(_Tunable):
     # overflow the workspace.  Queued tickets are then cut into PASSES of `pass_tickets` tickets (VTD_TROCR_PASS_TICKETS, default 2);
     # every pass is ONE encoder pass into an encoder-output slot and ONE decode.
     #
-    # Overlap (default; VTD_TROCR_OVERLAP=0 for the back-to-back order): the handle has two slots, and the encoder pass of pass k+1
-    # runs BESIDE the decode of pass k -- each on a stream of its own whose kernels are confined to a disjoint part of the chip
-    # (include/vtd.h: vtd_stream_create_masked; VTD_TROCR_DEC_CUS of the 256 CUs for the decode, the rest for the encoder pass).  On
-    # plain streams this lost (round 3: the decoder's ~6.7 k small dependent launches queued for CU slots behind the encoder's wide
-    # ones, 10 -> 50 us each, and the encoder pass doubled: 225 ms for the pair against 165 ms back to back); with the chip
-    # partitioned every decode launch finds its CUs free.  For the two to overlap the host must have pass k+1 queued when it starts
-    # pass k's (host-paced) decode, i.e. a caller keeps `pipeline_lag` = 2 pass_tickets - 1 tickets in flight behind the one it asks
-    # for (VideoTextPipeline._pipeline_push and bench.py do); with fewer the passes simply run back to back as before.
+    # A caller keeps `pipeline_lag` = pass_tickets - 1 tickets in flight behind the one it asks for (VideoTextPipeline._pipeline_push and
+    # bench.py do), so that a whole pass is queued when its first ticket is finished; with fewer in flight the passes are simply smaller.
+    #
+    # Overlap (VTD_TROCR_OVERLAP=1, off by default): the handle has two slots, and the encoder pass of pass k+1 can run BESIDE the
+    # decode of pass k -- each on a stream of its own whose kernels are confined to a disjoint part of the chip (include/vtd.h:
+    # vtd_stream_create_masked; VTD_TROCR_DEC_CUS of the 256 CUs for the decode, the rest for the encoder pass; pipeline_lag is then
+    # 2 pass_tickets - 1).  Measured twice, lost twice: on plain streams (round 3) the decoder's ~6.7 k small
+    # dependent launches queued for CU slots behind the encoder's wide ones (10 -> 50 us each) and the encoder pass doubled; with the
+    # chip really partitioned (round 4: 32 / 64 / 96 / 128 CUs for the decode) every decode launch finds its CUs free, but the decode's
+    # kernels are sized to finish in ONE round on 256 CUs -- on a quarter of the chip each takes several -- and the encoder pass loses
+    # the same share: 135 - 238 frames/s against 279 back to back on the ResNet-18 line.  The mode stays as a tested option.
     def _setup_overlap(self):
         self.pass_tickets = max(1, int(os.environ.get("VTD_TROCR_PASS_TICKETS", "2")))
         self.overlap = False
         self._enc_stream = self._dec_stream = None
-        if os.environ.get("VTD_TROCR_OVERLAP", "1") != "0" and self.slots >= 2:
+        if os.environ.get("VTD_TROCR_OVERLAP", "0") == "1" and self.slots >= 2:
             try:
                 total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
                 dec_cus = min(max(8, int(os.environ.get("VTD_TROCR_DEC_CUS", "80"))), total - 8)
-                self._enc_stream, self._dec_stream = _masked_stream_pair(self.lib, torch.cuda.current_device(), total, dec_cus)
+                self._enc_stream, self._dec_stream, dec_cus = _masked_stream_pair(self.lib, torch.cuda.current_device(), total, dec_cus)
                 self.overlap = True
                 self.dec_cus, self.enc_cus = dec_cus, total - dec_cus
             except Exception as e:   # no CU masks on this stack: the back-to-back order
                 logger.warning(f"TrOCREngine: CU-masked streams unavailable ({e}); encoder pass and decode run back to back")
                 self._enc_stream = self._dec_stream = None
-        self.pipeline_lag = 2 * self.pass_tickets - 1 if self.overlap else 1
+        self.pipeline_lag = 2 * self.pass_tickets - 1 if self.overlap else max(1, self.pass_tickets - 1)
 
     def submit_crops(self, frames, boxes):
         """Queue the crops `boxes` ([(frame, x1, y1, x2, y2), ...]) of a resident frame batch; returns a ticket for ``finish``.  Nothing

@@ -259,6 +259,7 @@ class VideoTextPipeline:
                 # the reference's detect() swallows its errors and yields [] for that frame (text_detector.py:139-141): a batch
                 # that cannot be enqueued degrades to empty detections for its frames, the video goes on
                 logger.error(f"Detection failed: {e}")
+                self._count_error("detection")
                 job["failed"] = True
             self._route_count("device", len(idx))
             self._inflight.append(job)
@@ -293,7 +294,14 @@ class VideoTextPipeline:
             job["det_tick"] = tick
         except Exception as e:
             logger.error(f"Detection failed: {e}")
+            self._count_error("detection")
             job["failed"] = True
+
+    def _count_error(self, kind):
+        """The reference's error convention swallows failures (log + empty result); a caller that must not mistake them for results
+        (bench.py) reads them here: {'detection': n, 'recognition': n, 'collection': n}."""
+        counts = self.__dict__.setdefault("error_counts", {})
+        counts[kind] = counts.get(kind, 0) + 1
 
     def _route_count(self, route, n):
         counts = self.__dict__.setdefault("route_counts", {"device": 0, "reference": 0})
@@ -306,6 +314,7 @@ class VideoTextPipeline:
             self.submit_recognition(job)
         except Exception as e:
             logger.error(f"Detection failed: {e}")
+            self._count_error("detection")
             job["failed"] = True
 
     def _retire(self, job) -> List[Dict]:
@@ -319,6 +328,7 @@ class VideoTextPipeline:
                 res = self.collect(job, job["info"])
             except Exception as e:
                 logger.error(f"Batch collection failed: {e}")
+                self._count_error("collection")
         if res is None:
             res = [{"frame_number": num, "timestamp": ts, "detections": []} for num, ts in job["info"]]
         if job.get("host") is not None:
@@ -420,6 +430,7 @@ class VideoTextPipeline:
                     rec = self.recognizer.submit_boxes(job["batch"], boxes)
         except Exception as e:
             logger.error(f"CRNN batch recognition failed: {e}")
+            self._count_error("recognition")
             rec, job["rec_failed"] = None, True
         job.update(detections=detections, owners=owners, rec=rec)
         return job
@@ -440,6 +451,7 @@ class VideoTextPipeline:
             texts = self.recognizer.finish_boxes(job["rec"])
         except Exception as e:   # text_recognizer.py:138-140: log, empty text, zero confidence, detections kept
             logger.error(f"CRNN batch recognition failed: {e}")
+            self._count_error("recognition")
             texts = [{"text": "", "confidence": 0.0}] * len(job["owners"])
         per_frame = [[] for _ in range(n)]
         for (i, j), rec in zip(job["owners"], texts):
