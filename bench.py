@@ -191,7 +191,8 @@ def main():
     from vtd_amd.pipeline import VideoTextPipeline
     os.environ["VTD_MAX_BATCH"] = str(B)
     if args.recognizer == "trocr":
-        os.environ.setdefault("VTD_TROCR_MAX_CROPS", "1024" if B <= 32 else "2048")   # two steps' crops share one recogniser pass
+        os.environ.setdefault("VTD_TROCR_PASS_TICKETS", "4")                          # four steps' crops share one recogniser pass
+        os.environ.setdefault("VTD_TROCR_MAX_CROPS", "1280" if B <= 32 else "2560")
         os.environ.setdefault("VTD_TROCR_SEEDED", "0")   # explicit opt-in: the architecture on synthetic weights (nothing is fetchable)
     pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64

@@ -184,6 +184,10 @@ typedef struct vtd_trocr_config {
 } vtd_trocr_config;
 int vtd_trocr_create(const vtd_trocr_config* cfg, int max_crops, vtd_trocr** out);
 void vtd_trocr_destroy(vtd_trocr* t);
+/* Build options, before finalize.  "slots" (1 or 2, default 1): encoder-output slots (cross-attention keys / values of all decoder
+ * layers, 28 MB per crop each).  With 2, vtd_trocr_encode_*_slot(1) may run while slot 0 still waits for or runs its decode (events
+ * inside the handle order the passes); the *_slot entry points reject slot indices >= the configured count. */
+int vtd_trocr_set_option(vtd_trocr* t, const char* name, int value);
 /* One tensor of VisionEncoderDecoderModel.state_dict() (text_recognizer.py:42): "encoder.embeddings.*",
  * "encoder.encoder.layer.N.*", "encoder.layernorm.*", "decoder.model.decoder.*", "decoder.output_projection.weight" (optional: tied to
  * embed_tokens when absent); "encoder.pooler.*" is accepted and ignored.  float32, PyTorch memory order. */

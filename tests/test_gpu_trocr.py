@@ -33,7 +33,7 @@ def tiny(hip):
 def base(hip):
     from vtd_amd.engine import TrOCREngine
     sd = weights.trocr_state_dict(BASE_PRINTED, seed=0)
-    eng = TrOCREngine(BASE_PRINTED, sd, max_crops=16)
+    eng = TrOCREngine(BASE_PRINTED, sd, max_crops=16, slots=2)   # (two encoder-output slots: the slot-independence test uses both)
     yield eng, sd
     eng.close()
 

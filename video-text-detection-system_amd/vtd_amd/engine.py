@@ -486,12 +486,12 @@ class TrOCREngine(_Tunable):
 
     _kind = "trocr"
 
-    def __init__(self, spec, state_dict, max_crops=None):
+    def __init__(self, spec, state_dict, max_crops=None, slots=None):
         from .trocr_spec import hf4_key
         self.lib = _native.require()
         self.spec = spec
-        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~75 MB of HBM each: two
-                                                                                            # encoder-output slots of 28 MB per row + workspaces)
+        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~47 MB of HBM each: one
+                                                                                            # encoder-output slot of 28 MB per row + workspaces; 75 MB with two slots)
         self.lock = threading.Lock()
         cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
                                   int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
@@ -501,6 +501,9 @@ class TrOCREngine(_Tunable):
         _native.check(self.lib.vtd_trocr_create(C.byref(cfg), self.max_crops, C.byref(h)), "vtd_trocr_create")
         self.handle = h
         try:
+            # one encoder-output slot unless the overlapped order (two passes in flight) or a caller asks for the second one
+            want_slots = slots or (2 if os.environ.get("VTD_TROCR_OVERLAP", "0") == "1" else 1)
+            _native.check(self.lib.vtd_trocr_set_option(h, b"slots", int(want_slots)), "vtd_trocr_set_option(slots)")
             for key, value in state_dict.items():
                 arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
                 _native.check(self.lib.vtd_trocr_set_tensor(h, hf4_key(key).encode(), arr.ctypes.data, arr.size), f"vtd_trocr_set_tensor({key})")
