@@ -13,3 +13,4 @@ rows=list(csv.DictReader(open("gpurun_out/rec/stats/run_kernel_stats.csv")))
 for r in sorted(rows,key=lambda r:-float(r['TotalDurationNs']))[:14]:
     print("%6d calls %8.1f us avg %9.1f us per forward  %s" % (int(r['Calls']), float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/23/1e3, r['Name'][:90]))
 PY
+python tools/rec_layers.py $(ls $out/stats/*kernel_trace.csv | head -1) 23

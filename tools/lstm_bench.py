@@ -5,7 +5,7 @@ from vtd_amd import nets
 from vtd_amd.engine import RecognizerEngine
 sd = nets.seeded_state_dict(lambda: nets.CRNN(97), seed=11)
 eng = RecognizerEngine(97, sd, max_crops=512)
-x = torch.rand(272, 3, 32, 128)
+x = torch.rand(int(os.environ.get("REC_CROPS", "272")), 3, 32, 128)
 for _ in range(3): eng.forward_logits(x)
 torch.cuda.synchronize()
 t=time.perf_counter()

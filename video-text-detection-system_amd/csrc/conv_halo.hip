@@ -31,6 +31,8 @@ struct HaloParams {
     int in_hp, in_wp, in_ring, out_hp, out_wp, out_ring, res_hp, res_wp, res_ring;
     int tiles_x, tiles_y, tiles_n, relu;
     unsigned long long* stamps;  // debug (VTD_HALO_STAMPS=1): 4 s_memtime stamps per workgroup
+    int dbg;                     // instrumented build only (-DVTD_CONV_EXPERIMENT, VTD_C64_DEBUG): 1 = every pixel block of a workgroup reads and
+                                 // writes ONE block's addresses (operands out of L2, results wrong): the layer-1 kernel without its HBM traffic
 };
 
 template <int N>
@@ -664,7 +666,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_duo_kernel(const HaloParam
     const int nq = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nmine = (nq - g + 1) >> 1;
     const int phases = 2 * ((nq + 1) >> 1) > 2 * (nq >> 1) + 1 ? 2 * ((nq + 1) >> 1) : 2 * (nq >> 1) + 1;
+#ifdef VTD_CONV_EXPERIMENT   // timing only: what the kernel costs when nothing it touches has to come from (or go to) HBM
+    auto block_of = [&](int i) { return p.dbg == 1 ? (int)blockIdx.x : (int)blockIdx.x + (2 * i + g) * (int)gridDim.x; };
+#else
     auto block_of = [&](int i) { return (int)blockIdx.x + (2 * i + g) * (int)gridDim.x; };
+#endif
 
     if (nmine > 0) issue_halo(block_of(0));
     hl_wait_vmcnt<0>();               // weights (every wave's share) and the first halo
@@ -733,6 +739,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_duo_kernel(const HaloParam
             // ---- service phase: finish block i, fetch the halo of block i + 1, wait for it (the partner group is multiplying)
             const int i = (phase - g - 1) >> 1;
             if (phase - g - 1 >= 0 && i < nmine) {
+                // The next halo leaves FIRST (this group's halo buffer is free: its K loop ended before the barrier just passed), so its
+                // round trip runs under the epilogue's converts and stores instead of behind them.  (Round 4, tools/gpu_l1_bound.sh: with
+                // every operand served from L2 the four layer-1 launches still took 56 / 66 us against 59 / 78 -- the phases were bound by
+                // this service phase's serial store -> fetch -> wait chain, not by HBM bytes.)
+                if (i + 1 < nmine) issue_halo(block_of(i + 1));
                 int img, y0, x0;
                 tile_coords(block_of(i), img, y0, x0);
                 half_t* obase = p.out + ((int64_t)(img * p.out_hp + y0 + p.out_ring) * p.out_wp + x0 + p.out_ring) * 64;
@@ -749,7 +760,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_duo_kernel(const HaloParam
                         }
                         *(half8*)(obase + (px_row(j) * p.out_wp + px_col(j)) * 64 + fq * 16 + h * 8) = hv;
                     }
-                if (i + 1 < nmine) issue_halo(block_of(i + 1));
             }
             hl_wait_vmcnt<0>();
         }
@@ -794,6 +804,17 @@ int c64_launch(const HaloParams& p, hipStream_t stream) {
     }
     const char* duo_env = getenv("VTD_C64_DUO");  // tests: 0 = the one-group kernel (read per launch so a test can flip it)
     const bool duo = !(duo_env && duo_env[0] == '0');
+#ifdef VTD_CONV_EXPERIMENT
+    if (duo) {
+        HaloParams q = p;
+        const char* d = getenv("VTD_C64_DEBUG");
+        q.dbg = d ? atoi(d) : 0;
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_duo_kernel<TW, RELU, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return -(int)e;
+        hipLaunchKernelGGL((conv3x3_c64_duo_kernel<TW, RELU, RES>), dim3(grid), dim3(512), lds, stream, q);
+        return -(int)hipGetLastError();
+    }
+#endif
     if (duo) {
         static bool attr_duo = false;
         if (!attr_duo) {
@@ -890,6 +911,7 @@ int vtd_launch_conv_halo(const ConvParams& c, int bn, int tw, hipStream_t stream
     p.res_hp = c.res_hp; p.res_wp = c.res_wp; p.res_ring = c.res_ring;
     p.relu = (c.flags & EPI_RELU) ? 1 : 0;
     p.stamps = nullptr;
+    p.dbg = 0;
     if (c.in_y0 != c.in_x0 || c.in_y0 < 0 || c.K != 9 * c.in_c || c.out_c != c.cout || p.n <= 0 || (c.in_c & 63) || (c.cout & 63) ||
         (tw != 16 && tw != 32) || c.stride != 1 || c.M != p.n * c.ho * c.wo)
         return -2201;  // shapes are validated here: a mismatch must never reach a kernel

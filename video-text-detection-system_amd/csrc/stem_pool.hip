@@ -31,7 +31,7 @@ constexpr int SP_LDS = SP_NST * SP_PATCH_BYTES + 256 * SP_CT_PITCH + 256;
 
 struct StemPoolParams {
     const half_t* in;    // [n][in_hp][in_wp][4] fp16, ring 3
-    const half_t* w;     // [7 ky][4 cout tiles][64 lanes][8] fp16: lane (fr,fq) of tile i holds cout 16i+fr, taps 2fq,2fq+1, 4 ch
+    const half_t* w;     // [7 ky][4 cout tiles][64 lanes][8] fp16: lane (fr,fq) of tile i holds cout sp_chan(i, fr), taps 2fq,2fq+1, 4 ch
     const float* bias;   // [64]
     half_t* out;         // [n][out_hp][out_wp][64], ring out_ring
     int n, in_hp, in_wp, conv_h, conv_w, pool_h, pool_w, out_hp, out_wp, out_ring;
@@ -46,6 +46,13 @@ typedef short short8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ half8 sp_max(half8 a, half8 b) {
     return __builtin_bit_cast(half8, __builtin_elementwise_max(__builtin_bit_cast(short8v, a), __builtin_bit_cast(short8v, b)));
 }
+
+// MFMA row fr of cout tile i carries this output channel: permuted so that a lane's accumulators of a tile PAIR are 8 consecutive
+// channels -- acc[2k][.][e] and acc[2k+1][.][e] of lane group fq = channels 32k + 8fq + e and 32k + 8fq + 4 + e -- and the conv tile
+// goes to LDS as one 16-byte chunk per (pixel, pair) instead of two 8-byte halves.  ds_write_b64 is served in groups of 16 lanes:
+// 16 pixels at the 144-byte pitch put two lanes on every bank (SQ_LDS_BANK_CONFLICT: 40 % of this kernel's LDS cycles, round-3
+// counters); ds_write_b128's groups of 8 lanes cover 8 pixels x 16 bytes = all 32 banks once.
+__host__ __device__ constexpr int sp_chan(int tile, int row) { return 32 * (tile >> 1) + 8 * (row >> 2) + 4 * (tile & 1) + (row & 3); }
 
 template <int N>
 __device__ __forceinline__ void sp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = *(const floatx4*)(bias_lds + i * 16 + fq * 4);
+            for (int j = 0; j < 4; ++j) acc[i][j] = *(const floatx4*)(bias_lds + sp_chan(i, fq * 4));
         const unsigned char* pb = ring + st * SP_PATCH_BYTES;
         // software pipeline by hand: the fragments of kernel row ky+1 are read while row ky multiplies; the scheduling
         // barriers stop the compiler from hoisting all 28 LDS reads (which would blow the register budget)
@@ -197,17 +204,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
             const int c_row = pix / SP_CT_COLS, c_col = pix - c_row * SP_CT_COLS;
             const int cy = 2 * py0 - 1 + c_row, cx = 2 * px0 - 1 + c_col;
             const bool valid = cy >= 0 && cy < p.conv_h && cx >= 0 && cx < p.conv_w;
-            unsigned char* dst = ctile + pix * SP_CT_PITCH + fq * 8;
+            unsigned char* dst = ctile + pix * SP_CT_PITCH + fq * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int k = 0; k < 2; ++k) {
                 typedef float float2v __attribute__((ext_vector_type(2)));
                 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                const half2v lo = __builtin_convertvector((float2v{acc[i][j][0], acc[i][j][1]}), half2v);  // v_cvt_pk_f16_f32
-                const half2v hi = __builtin_convertvector((float2v{acc[i][j][2], acc[i][j][3]}), half2v);
-                half4 hv = half4{lo[0], lo[1], hi[0], hi[1]};
-                hv = __builtin_bit_cast(half4, __builtin_elementwise_max(__builtin_bit_cast(short4v, hv), short4v{0, 0, 0, 0}));
-                if (!valid) hv = half4{0, 0, 0, 0};
-                *(half4*)(dst + i * 32) = hv;
+                const floatx4 a = acc[2 * k][j], b = acc[2 * k + 1][j];
+                const half2v h0 = __builtin_convertvector((float2v{a[0], a[1]}), half2v);  // v_cvt_pk_f16_f32
+                const half2v h1 = __builtin_convertvector((float2v{a[2], a[3]}), half2v);
+                const half2v h2 = __builtin_convertvector((float2v{b[0], b[1]}), half2v);
+                const half2v h3 = __builtin_convertvector((float2v{b[2], b[3]}), half2v);
+                half8 hv = half8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+                hv = __builtin_bit_cast(half8, __builtin_elementwise_max(__builtin_bit_cast(short8v, hv), short8v{0, 0, 0, 0, 0, 0, 0, 0}));
+                if (!valid) hv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                *(half8*)(dst + k * 64) = hv;   // channels 32k + 8fq .. + 7: chunk 4k + fq of the pixel
             }
         }
         sp_lds_barrier();
@@ -259,7 +269,7 @@ void vtd_stem_pool_pack_weights(const float* w_folded /* [64][3][7][7] already s
     for (int ky = 0; ky < 7; ++ky)
         for (int i = 0; i < 4; ++i)
             for (int lane = 0; lane < 64; ++lane) {
-                const int fr = lane & 15, fq = lane >> 4, co = i * 16 + fr;
+                const int fr = lane & 15, fq = lane >> 4, co = sp_chan(i, fr);
                 for (int e = 0; e < 8; ++e) {
                     const int kx = 2 * fq + (e >> 2), c = e & 3;
                     float v = 0.f;

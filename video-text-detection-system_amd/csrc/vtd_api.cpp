@@ -198,24 +198,43 @@ static bool halo_enabled() {
     return !(e && e[0] == '0');
 }
 
-// Configurations 0 / 12 / 13 are one kernel family (8 waves, 128 channels wide, 3 stages) at tile heights 256 / 208 / 272.  Which
-// height is cheapest depends on how the launch's tile count falls on the 256 CUs (one workgroup each), i.e. on the ACTUAL row count,
-// which a per-bucket table cannot know (272 crops and 512 crops share a bucket): rounds x time per tile.  Time per tile = height /
-// relative MFMA efficiency of the wave layout, measured on layer 2-4 and the CRNN (tools/gpu_tiles.sh): 4 x 2 waves of 64 x 64
-// (256 rows) 1.0, 2 x 4 waves of 9+8 fragments x 32 (272 rows) 0.92, 7+6 x 32 (208 rows) 0.80.  A pure function of the shape, and
-// tile height never changes a bit of the result (tests/test_gpu_detector.py: test_implicit_gemm_tile_heights_bit_identical).
+// Configurations 0 / 12 / 13 / 14 / 15 are one kernel family (128 or 256 channels wide, 3- or 2-stage ring) at tile heights 256 / 208 /
+// 272 rows, on 8 or 16 waves.  Which is cheapest depends on how the launch's tile count falls on the 256 CUs (one workgroup each), i.e.
+// on the ACTUAL row count, which a per-bucket table cannot know (272 crops and 512 crops share a bucket; the table's entry was timed at
+// 512): rounds x time per tile.  Time per tile = rows x columns / relative efficiency of the shape, measured on layer 2-4 and on the
+// CRNN at 272 and 301 crops with every convolution forced onto each shape in turn (tools/gpu_rec_cfgs.sh, round 4): 4 x 2 waves of
+// 64 x 64 (cfg 0) 1.0, the same tile on 16 waves (14) 1.04, 2 x 4 waves of 9+8 fragments x 32 (13: 272 rows) 0.92, 7+6 x 32 (12: 208 rows)
+// 0.80, the 256 x 256 tile (15) 1.07.  What that buys at 272 crops: conv5 (34 816 rows x 512 channels; the table's 256 x 256 tile makes
+// 272 tiles = two rounds for 1.06) 130 -> 85 us on 272-row tiles (512 tiles = two full rounds), conv3 / conv4 / conv6 58 / 99 / 177 ->
+// 52 / 87 / 152 us; at 301 crops the 16-wave 256-row tile wins instead and conv5 takes 99 us.  The table's entry is tried first and
+// keeps the slot unless another shape is cheaper by more than 6 % (short-K launches have per-tile overheads the model does not see).
+// A pure function of the shape, and the tile shape never changes a bit of the result
+// (tests/test_gpu_detector.py: test_implicit_gemm_tile_heights_bit_identical).
 static int pick_tile_height(const ConvParams& p, int table_cfg) {
     if (const char* e = std::getenv("VTD_TILE_HEIGHT_MODEL"); e && e[0] == '0') return table_cfg;
     if (std::getenv("VTD_FORCE_CONV_CFG")) return table_cfg;  // tests pin one configuration
-    static const struct { int cfg, bm; double eff; } cand[3] = {{0, 256, 1.0}, {13, 272, 0.92}, {12, 208, 0.80}};
+    static const struct { int cfg, bm, bn; double eff; } family[5] = {{0, 256, 128, 1.0}, {14, 256, 128, 1.04}, {13, 272, 128, 0.92}, {12, 208, 128, 0.80},
+                                                                      {15, 256, 256, 1.07}};
+    auto cost_of = [&](int cfg) -> double {
+        for (const auto& k : family)
+            if (k.cfg == cfg) {
+                if (!vtd_conv_config_valid(p, k.cfg)) return 0.0;
+                const int64_t tiles = (int64_t)((p.M + k.bm - 1) / k.bm) * (p.cout_pad / k.bn);
+                return (double)((tiles + 255) / 256) * k.bm * k.bn / k.eff;
+            }
+        return 0.0;
+    };
     int best = table_cfg;
-    double best_cost = 0.0;
-    for (const auto& k : cand) {
-        if (!vtd_conv_config_valid(p, k.cfg)) continue;
-        const int64_t tiles = (int64_t)((p.M + k.bm - 1) / k.bm) * (p.cout_pad / 128);
-        const double cost = (double)((tiles + 255) / 256) * k.bm / k.eff;
-        if (best_cost == 0.0 || cost < best_cost * 0.97) { best_cost = cost; best = k.cfg; }  // 3 % hysteresis in favour of the earlier candidate
+    double best_cost = cost_of(table_cfg);
+    if (best_cost == 0.0) return table_cfg;
+    const double keep = best_cost * 0.94;   // another shape must beat the table's by more than 6 %
+    double other_cost = keep;
+    for (const auto& k : family) {
+        if (k.cfg == table_cfg) continue;
+        const double c = cost_of(k.cfg);
+        if (c > 0.0 && c < other_cost) { other_cost = c; best = k.cfg; }
     }
+    (void)best_cost;
     return best;
 }
 
@@ -245,7 +264,7 @@ static int launch_conv_op(const ConvOp& c, int n, hipStream_t s, int cfg = -1, f
         return vtd_launch_conv_halo(p, cfg == kHaloC64Cfg ? 1 : cfg == kHalo64Cfg ? 2 : bn, tw, s);
     }
     if (cfg == kPointwiseCfg) return vtd_launch_pointwise128(p, s);
-    if (!c.plist && (cfg == 0 || cfg == 12 || cfg == 13)) cfg = pick_tile_height(p, cfg);
+    if (!c.plist && (cfg == 0 || cfg == 12 || cfg == 13 || cfg == 14 || cfg == 15)) cfg = pick_tile_height(p, cfg);
     return vtd_launch_conv(p, cfg, s);
 }
 
