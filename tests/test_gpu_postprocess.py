@@ -11,6 +11,13 @@ from vtd_amd._fixtures import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["frame-kernel", "ten-launches"])
+def pp_mode(request, monkeypatch):
+    """Every case runs on the one-workgroup-per-frame kernel (default) and on the ten launches it replaces (VTD_PP_FUSED=0): both must
+    match the oracle bit for bit, so they match one another."""
+    monkeypatch.setenv("VTD_PP_FUSED", "1" if request.param == "frame-kernel" else "0")
+
+
 def _check(pp, maps, sizes, thr):
     prob = torch.from_numpy(np.stack(maps)).cuda()
     got = pp.run(prob, [s[0] for s in sizes], [s[1] for s in sizes], thr, debug=True)

@@ -17,6 +17,7 @@
 //                          surviving detections are emitted in reverse raster order (cv2 4.8.1's order)
 // All stages are HBM/L2-bound integer work; no host synchronisation happens between them.
 #include <float.h>
+#include <stdlib.h>
 #include <math.h>
 #include <vector>
 
@@ -120,21 +121,28 @@ __device__ __forceinline__ uint64_t first_run(uint64_t m, int* i0, int* len) {
 // is the packed word and gives every lane the start of its same-class run, carried across word seams, which becomes its
 // initial union-find parent.  Horizontal connectivity therefore costs no atomics at all, and the (usually huge) frame
 // background collapses to one run per row instead of one node per pixel.
-__global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
-    const int lane = threadIdx.x & 63;
-    const int64_t total = (int64_t)ws.n * ws.h;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t ri = wave0; ri < total; ri += nwaves) {
-        const int f = (int)(ri / ws.h), y = (int)(ri - (int64_t)f * ws.h);
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        int carry_start = 0;      // x of the start of the run that reaches the previous word's last pixel
-        bool carry_fg = false;
-        for (int seg = 0; seg < ws.wpr; ++seg) {
+__device__ __forceinline__ void pp_init_row(const PostWs& ws, int f, int y, int lane) {
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    int carry_start = 0;      // x of the start of the run that reaches the previous word's last pixel
+    bool carry_fg = false;
+    const float* prow = ws.prob + (int64_t)f * ws.P + (int64_t)y * ws.w;
+    // the row's words are fetched 16 at a time before any of them is processed: one memory round trip per 1024 pixels instead of one
+    // per word (the per-frame kernel below has 16 waves for a whole map: nobody else covers a dependent chain of round trips)
+    for (int s0 = 0; s0 < ws.wpr; s0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = (s0 + k) * 64 + lane;
+            v[k] = (s0 + k < ws.wpr && x < ws.w) ? prow[x] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int seg = s0 + k;
+            if (seg >= ws.wpr) continue;   // (wave-uniform)
             const int x = seg * 64 + lane;
             const bool valid = x < ws.w;
             const int pix = y * ws.w + x;
-            const bool fg = valid && (ws.prob[(int64_t)f * ws.P + pix] > ws.thr);
+            const bool fg = valid && (v[k] > ws.thr);
             const unsigned long long m = __ballot(fg);
             const unsigned long long same = fg ? m : ~m;
             const unsigned long long below = lane ? (~same & ((1ull << lane) - 1ull)) : 0ull;
@@ -150,7 +158,18 @@ __global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
             carry_fg = (m >> 63) & 1;
             if (lane == 0) ws.fgbits[((int64_t)f * ws.h + y) * ws.wpr + seg] = m;
         }
-        if (y == 0 && lane == 0) L[0] = 0;
+    }
+    if (y == 0 && lane == 0) L[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)ws.n * ws.h;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t ri = wave0; ri < total; ri += nwaves) {
+        const int f = (int)(ri / ws.h), y = (int)(ri - (int64_t)f * ws.h);
+        pp_init_row(ws, f, y, lane);
     }
 }
 
@@ -159,76 +178,88 @@ __global__ __launch_bounds__(256) void pp_init(const PostWs ws) {
     for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < total_words; wi += (int64_t)gridDim.x * blockDim.x)
 
 // ---- stage 2: join runs.  Only the first column of every run-to-run contact issues a union.
+__device__ __forceinline__ void pp_merge_fg_bg_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    const uint64_t* B = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const uint64_t vm = valid_mask(seg, ws.w, ws.wpr);
+    const Words3 cur = load3(B, y, seg, ws.h, ws.wpr), up = load3(B, y - 1, seg, ws.h, ws.wpr);
+    const int base = y * ws.w + seg * 64 + 1;  // label index of bit 0
+    if (seg == ws.wpr - 1 && !((cur.c >> ((ws.w - 1) & 63)) & 1)) uf_unite(L, base + ((ws.w - 1) & 63), 0);  // background at the right frame edge
+    if (y == 0) return;
+    const uint64_t W = west(cur), E = east(cur), N = up.c, NW = west(up), NE = east(up);
+    // foreground, 8-connected
+    uint64_t m = cur.c & N & ~(W & NW);
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+    m = cur.c & ~N & NW & ~W;
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
+    m = cur.c & ~N & NE & ~E;
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
+    // background, 4-connected (pixels left of the frame do not exist: bit 0 of word 0 has no west neighbour)
+    const uint64_t bg = ~cur.c & vm, bgN = ~up.c & vm;
+    const uint64_t bgW = (~cur.c << 1) | (seg > 0 ? (~cur.l) >> 63 : 0), bgNW = (~up.c << 1) | (seg > 0 ? (~up.l) >> 63 : 0);
+    m = bg & bgN & ~(bgW & bgNW);
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+}
+
 __global__ void pp_merge_fg_bg(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const uint64_t* B = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const uint64_t vm = valid_mask(seg, ws.w, ws.wpr);
-        const Words3 cur = load3(B, y, seg, ws.h, ws.wpr), up = load3(B, y - 1, seg, ws.h, ws.wpr);
-        const int base = y * ws.w + seg * 64 + 1;  // label index of bit 0
-        if (seg == ws.wpr - 1 && !((cur.c >> ((ws.w - 1) & 63)) & 1)) uf_unite(L, base + ((ws.w - 1) & 63), 0);  // background at the right frame edge
-        if (y == 0) continue;
-        const uint64_t W = west(cur), E = east(cur), N = up.c, NW = west(up), NE = east(up);
-        // foreground, 8-connected
-        uint64_t m = cur.c & N & ~(W & NW);
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
-        m = cur.c & ~N & NW & ~W;
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
-        m = cur.c & ~N & NE & ~E;
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
-        // background, 4-connected (pixels left of the frame do not exist: bit 0 of word 0 has no west neighbour)
-        const uint64_t bg = ~cur.c & vm, bgN = ~up.c & vm;
-        const uint64_t bgW = (~cur.c << 1) | (seg > 0 ? (~cur.l) >> 63 : 0), bgNW = (~up.c << 1) | (seg > 0 ? (~up.l) >> 63 : 0);
-        m = bg & bgN & ~(bgW & bgNW);
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+        pp_merge_fg_bg_word(ws, f, y, seg, wi);
     }
 }
 
 // ---- stage 3a: background runs that do not reach the frame background are holes -> inside mask
+__device__ __forceinline__ void pp_classify_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const uint64_t cur = ws.fgbits[wi];
+    uint64_t bg = ~cur & valid_mask(seg, ws.w, ws.wpr), holes = 0;
+    const int base = y * ws.w + seg * 64 + 1;
+    while (bg) {
+        int i0, len;
+        const uint64_t run = first_run(bg, &i0, &len);
+        if (uf_find(L, base + i0) != 0) holes |= run;
+        bg &= ~run;
+    }
+    ws.inbits[wi] = cur | holes;
+}
+
 __global__ void pp_classify(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const uint64_t cur = ws.fgbits[wi];
-        uint64_t bg = ~cur & valid_mask(seg, ws.w, ws.wpr), holes = 0;
-        const int base = y * ws.w + seg * 64 + 1;
-        while (bg) {
-            int i0, len;
-            const uint64_t run = first_run(bg, &i0, &len);
-            if (uf_find(L, base + i0) != 0) holes |= run;
-            bg &= ~run;
-        }
-        ws.inbits[wi] = cur | holes;
+        pp_classify_word(ws, f, y, seg, wi);
     }
 }
 
 // ---- stage 3b: filled components = foreground + holes + islands.  Same-class neighbours are already joined (diagonal
 // hole pixels always share a 4-connected or foreground bridge), so only class changes need unions.
+__device__ __forceinline__ void pp_merge_inside_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    const uint64_t* F = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
+    const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const Words3 fc = load3(F, y, seg, ws.h, ws.wpr), fu = load3(F, y - 1, seg, ws.h, ws.wpr);
+    const Words3 ic = load3(I, y, seg, ws.h, ws.wpr), iu = load3(I, y - 1, seg, ws.h, ws.wpr);
+    if (!ic.c) return;
+    const int base = y * ws.w + seg * 64 + 1;
+    uint64_t m = ic.c & west(ic) & (fc.c ^ west(fc));
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - 1); }
+    m = ic.c & iu.c & (fc.c ^ fu.c);
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
+    m = ic.c & west(iu) & (fc.c ^ west(fu));
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
+    m = ic.c & east(iu) & (fc.c ^ east(fu));
+    while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
+}
+
 __global__ void pp_merge_inside(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const uint64_t* F = ws.fgbits + (int64_t)f * ws.h * ws.wpr;
-        const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const Words3 fc = load3(F, y, seg, ws.h, ws.wpr), fu = load3(F, y - 1, seg, ws.h, ws.wpr);
-        const Words3 ic = load3(I, y, seg, ws.h, ws.wpr), iu = load3(I, y - 1, seg, ws.h, ws.wpr);
-        if (!ic.c) continue;
-        const int base = y * ws.w + seg * 64 + 1;
-        uint64_t m = ic.c & west(ic) & (fc.c ^ west(fc));
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - 1); }
-        m = ic.c & iu.c & (fc.c ^ fu.c);
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w); }
-        m = ic.c & west(iu) & (fc.c ^ west(fu));
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w - 1); }
-        m = ic.c & east(iu) & (fc.c ^ east(fu));
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; uf_unite(L, base + i, base + i - ws.w + 1); }
+        pp_merge_inside_word(ws, f, y, seg, wi);
     }
 }
 
@@ -236,23 +267,27 @@ __global__ void pp_merge_inside(const PostWs ws) {
 // only those are examined (and path-compressed), counted per word, scanned per frame and numbered in raster order.
 __device__ __forceinline__ uint64_t fg_run_starts(uint64_t cur) { return cur & ~(cur << 1); }
 
+__device__ __forceinline__ void pp_count_roots_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const int base = y * ws.w + seg * 64 + 1;
+    uint64_t m = fg_run_starts(ws.fgbits[wi]);
+    int cnt = 0;
+    while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int r = uf_find(L, base + i);
+        L[base + i] = r;
+        cnt += r == base + i;
+    }
+    ws.slice_count[wi] = cnt;
+}
+
 __global__ void pp_count_roots(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const int base = y * ws.w + seg * 64 + 1;
-        uint64_t m = fg_run_starts(ws.fgbits[wi]);
-        int cnt = 0;
-        while (m) {
-            const int i = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int r = uf_find(L, base + i);
-            L[base + i] = r;
-            cnt += r == base + i;
-        }
-        ws.slice_count[wi] = cnt;
+        pp_count_roots_word(ws, f, y, seg, wi);
     }
 }
 
@@ -275,9 +310,7 @@ __device__ int block_exclusive_scan(int v, int* sh /* [2*SCAN_THREADS] */, int* 
 }
 
 // one block per frame: exclusive scan of the per-word root counts (raster order), reset the per-component accumulators
-__global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) {
-    __shared__ int sh[2 * SCAN_THREADS];
-    const int f = blockIdx.x;
+__device__ void pp_scan_slices_frame(const PostWs& ws, int f, int* sh /* [2 * SCAN_THREADS] */) {
     const int slices = ws.h * ws.wpr;
     int* cnt = ws.slice_count + (int64_t)f * slices;
     const int chunk = (slices + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -300,61 +333,72 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) 
     }
 }
 
+__global__ __launch_bounds__(SCAN_THREADS) void pp_scan_slices(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    pp_scan_slices_frame(ws, blockIdx.x, sh);
+}
+
+__device__ __forceinline__ void pp_number_components_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    const int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const int base = y * ws.w + seg * 64 + 1;
+    uint64_t m = fg_run_starts(ws.fgbits[wi]);
+    int next = ws.slice_count[wi];
+    while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (L[base + i] == base + i) ws.compid[(int64_t)f * ws.P + base + i - 1] = next++;
+    }
+}
+
 __global__ void pp_number_components(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const int base = y * ws.w + seg * 64 + 1;
-        uint64_t m = fg_run_starts(ws.fgbits[wi]);
-        int next = ws.slice_count[wi];
-        while (m) {
-            const int i = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (L[base + i] == base + i) ws.compid[(int64_t)f * ws.P + base + i - 1] = next++;
-        }
+        pp_number_components_word(ws, f, y, seg, wi);
     }
 }
 
 // ---- stage 5: per-component contour area (lattice identity) and bounding box, one set of atomics per inside run.
 // 2x2 blocks are anchored at their top-left pixel and credited to the run that owns the block's first inside pixel of the
 // top row (every block with >= 3 inside pixels has one).
+__device__ __forceinline__ void pp_stats_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
+    const Words3 a = load3(I, y, seg, ws.h, ws.wpr);
+    if (!a.c) return;
+    const Words3 b = load3(I, y + 1, seg, ws.h, ws.wpr);
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const uint64_t a1 = east(a), b1 = east(b);
+    const uint64_t four = a.c & a1 & b.c & b1;
+    const uint64_t three = (a.c & a1 & b.c & ~b1) | (a.c & a1 & ~b.c & b1) | (a.c & ~a1 & b.c & b1) | (~a.c & a1 & b.c & b1);
+    // block anchored on the last pixel of the previous word whose only missing corner is that pixel: owned by bit 0 here
+    const int carry = (seg > 0 && !(a.l >> 63) && (a.c & 1) && (b.l >> 63) && (b.c & 1)) ? 1 : 0;
+    const int base = y * ws.w + seg * 64 + 1;
+    uint64_t m = a.c;
+    while (m) {
+        int i0, len;
+        const uint64_t run = first_run(m, &i0, &len);
+        m &= ~run;
+        const uint64_t left = i0 > 0 ? 1ull << (i0 - 1) : 0ull;
+        const int add = 2 * __popcll(four & run) + __popcll(three & (run | left)) + (i0 == 0 ? carry : 0);
+        const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
+        if (add) atomicAdd(ws.area2 + (int64_t)f * ws.maxc + c, add);
+        int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
+        atomicMin(bb + 0, seg * 64 + i0); atomicMax(bb + 1, seg * 64 + i0 + len - 1); atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+    }
+}
+
 __global__ void pp_stats(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        const uint64_t* I = ws.inbits + (int64_t)f * ws.h * ws.wpr;
-        const Words3 a = load3(I, y, seg, ws.h, ws.wpr);
-        if (!a.c) continue;
-        const Words3 b = load3(I, y + 1, seg, ws.h, ws.wpr);
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const uint64_t a1 = east(a), b1 = east(b);
-        const uint64_t four = a.c & a1 & b.c & b1;
-        const uint64_t three = (a.c & a1 & b.c & ~b1) | (a.c & a1 & ~b.c & b1) | (a.c & ~a1 & b.c & b1) | (~a.c & a1 & b.c & b1);
-        // block anchored on the last pixel of the previous word whose only missing corner is that pixel: owned by bit 0 here
-        const int carry = (seg > 0 && !(a.l >> 63) && (a.c & 1) && (b.l >> 63) && (b.c & 1)) ? 1 : 0;
-        const int base = y * ws.w + seg * 64 + 1;
-        uint64_t m = a.c;
-        while (m) {
-            int i0, len;
-            const uint64_t run = first_run(m, &i0, &len);
-            m &= ~run;
-            const uint64_t left = i0 > 0 ? 1ull << (i0 - 1) : 0ull;
-            const int add = 2 * __popcll(four & run) + __popcll(three & (run | left)) + (i0 == 0 ? carry : 0);
-            const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
-            if (add) atomicAdd(ws.area2 + (int64_t)f * ws.maxc + c, add);
-            int* bb = ws.bbox + ((int64_t)f * ws.maxc + c) * 4;
-            atomicMin(bb + 0, seg * 64 + i0); atomicMax(bb + 1, seg * 64 + i0 + len - 1); atomicMin(bb + 2, y); atomicMax(bb + 3, y);
-        }
+        pp_stats_word(ws, f, y, seg, wi);
     }
 }
 
 // one block per frame: candidates (contourArea >= 100) in raster order + their row-table offsets
-__global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
-    __shared__ int sh[2 * SCAN_THREADS];
-    const int f = blockIdx.x;
+__device__ void pp_candidates_frame(const PostWs& ws, int f, int* sh /* [2 * SCAN_THREADS] */) {
     const int nc = ws.ncomp[f];
     const int* area2 = ws.area2 + (int64_t)f * ws.maxc;
     const int* bbox = ws.bbox + (int64_t)f * ws.maxc * 4;
@@ -385,26 +429,81 @@ __global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
     if (threadIdx.x == 0) ws.ncand[f] = min(tot_c, ws.maxcand);
 }
 
+__global__ __launch_bounds__(SCAN_THREADS) void pp_candidates(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    pp_candidates_frame(ws, blockIdx.x, sh);
+}
+
+__device__ __forceinline__ void pp_row_extents_word(const PostWs& ws, int f, int y, int seg, int64_t wi) {
+    int* L = ws.label + (int64_t)f * (ws.P + 1);
+    const int base = y * ws.w + seg * 64 + 1;
+    uint64_t m = ws.inbits[wi];
+    while (m) {
+        int i0, len;
+        const uint64_t run = first_run(m, &i0, &len);
+        m &= ~run;
+        const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
+        const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
+        if (off < 0) continue;
+        const int r = off + y - ws.bbox[((int64_t)f * ws.maxc + c) * 4 + 2];
+        atomicMin(ws.rowmin + (int64_t)f * ws.P + r, seg * 64 + i0);
+        atomicMax(ws.rowmax + (int64_t)f * ws.P + r, seg * 64 + i0 + len - 1);
+    }
+}
+
 __global__ void pp_row_extents(const PostWs ws) {
     PP_FOR_EACH_WORD(f, y, seg, wi) {
         const int f = (int)(wi / ((int64_t)ws.h * ws.wpr));
         const int rem = (int)(wi - (int64_t)f * ws.h * ws.wpr);
         const int y = rem / ws.wpr, seg = rem - y * ws.wpr;
-        int* L = ws.label + (int64_t)f * (ws.P + 1);
-        const int base = y * ws.w + seg * 64 + 1;
-        uint64_t m = ws.inbits[wi];
-        while (m) {
-            int i0, len;
-            const uint64_t run = first_run(m, &i0, &len);
-            m &= ~run;
-            const int c = ws.compid[(int64_t)f * ws.P + uf_find(L, base + i0) - 1];
-            const int off = ws.rowoff[(int64_t)f * ws.maxc + c];
-            if (off < 0) continue;
-            const int r = off + y - ws.bbox[((int64_t)f * ws.maxc + c) * 4 + 2];
-            atomicMin(ws.rowmin + (int64_t)f * ws.P + r, seg * 64 + i0);
-            atomicMax(ws.rowmax + (int64_t)f * ws.P + r, seg * 64 + i0 + len - 1);
-        }
+        pp_row_extents_word(ws, f, y, seg, wi);
     }
+}
+
+// ---- stages 1-6 of the chain above as ONE launch: a 1024-thread workgroup per frame.  The stages are loops over the frame's rows /
+// 64-pixel words with two per-frame scans in between, so the ten kernel boundaries become workgroup barriers -- the union-find still lives
+// in global memory (1.6 MB of labels per 640 x 640 map), its atomics still execute in L2.  What a boundary did besides ordering was
+// drop the CU's L1: a word a stage read (or initialised) with a plain access and another wave then changed by an L2 atomic must not be
+// served from that L1 to the next stage, so every stage change is barrier -> one wave invalidates the L1 (agent-scope acquire) ->
+// barrier.  Why: the ten launches were 0.3 ms of summed in-situ kernel time per batch, each spread thin over every CU the detector's and
+// the recogniser's wide kernels want (round-3 review); here a batch's post-process holds 16 waves on n CUs, once.
+__device__ __forceinline__ void pp_stage_sync() {
+    __syncthreads();   // every wave's stores and atomics of the stage have been issued and acknowledged (s_waitcnt vmcnt(0) in front of the barrier)
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void pp_frame_kernel(const PostWs ws) {
+    __shared__ int sh[2 * SCAN_THREADS];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int words = ws.h * ws.wpr;
+    const int64_t w0 = (int64_t)f * words;
+    for (int y = tid >> 6; y < ws.h; y += SCAN_THREADS / 64) pp_init_row(ws, f, y, lane);
+    pp_stage_sync();
+#define PP_FRAME_STAGE(fn)                                                    \
+    for (int i = tid; i < words; i += SCAN_THREADS) {                         \
+        const int y = i / ws.wpr, seg = i - y * ws.wpr;                       \
+        fn(ws, f, y, seg, w0 + i);                                            \
+    }                                                                         \
+    pp_stage_sync();
+    PP_FRAME_STAGE(pp_merge_fg_bg_word)
+    PP_FRAME_STAGE(pp_classify_word)
+    PP_FRAME_STAGE(pp_merge_inside_word)
+    PP_FRAME_STAGE(pp_count_roots_word)
+    pp_scan_slices_frame(ws, f, sh);
+    pp_stage_sync();
+    PP_FRAME_STAGE(pp_number_components_word)
+    PP_FRAME_STAGE(pp_stats_word)
+    pp_candidates_frame(ws, f, sh);
+    pp_stage_sync();
+    for (int i = tid; i < words; i += SCAN_THREADS) {
+        const int y = i / ws.wpr, seg = i - y * ws.wpr;
+        pp_row_extents_word(ws, f, y, seg, w0 + i);
+    }
+#undef PP_FRAME_STAGE
 }
 
 struct fpt { float x, y; };
@@ -765,16 +864,23 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     const int64_t words = (int64_t)n * ws.h * ws.wpr;
     const int iblocks = (int)std::min<int64_t>(((int64_t)n * ws.h + 3) / 4, 256 * 16);  // one wave per row
     const int wblocks = (int)std::min<int64_t>((words + 255) / 256, 256 * 16);      // one thread per word
-    hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_merge_fg_bg, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_classify, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_merge_inside, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_count_roots, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_scan_slices, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
-    hipLaunchKernelGGL(pp_number_components, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
-    hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
-    hipLaunchKernelGGL(pp_row_extents, dim3(wblocks), dim3(256), 0, s, ws);
+    // one workgroup per frame for everything up to the row tables (VTD_PP_FUSED=0: the ten launches it replaces; bit-identical results:
+    // tests/test_gpu_postprocess.py runs both)
+    const char* fe = getenv("VTD_PP_FUSED");
+    if (!(fe && fe[0] == '0')) {
+        hipLaunchKernelGGL(pp_frame_kernel, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+    } else {
+        hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_merge_fg_bg, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_classify, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_merge_inside, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_count_roots, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_scan_slices, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+        hipLaunchKernelGGL(pp_number_components, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_stats, dim3(wblocks), dim3(256), 0, s, ws);
+        hipLaunchKernelGGL(pp_candidates, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
+        hipLaunchKernelGGL(pp_row_extents, dim3(wblocks), dim3(256), 0, s, ws);
+    }
     const size_t box_lds = ((size_t)3 * ws.h + (size_t)5 * (2 * ws.h + 2)) * sizeof(int);  // row table, flags, hull points, vect, inv_len
     if (box_lds > 150 * 1024) return -1011;
     static bool box_attr = false;
