@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["frame-kernel", "ten-launches"])
 def pp_mode(request, monkeypatch):
-    """Every case runs on the one-workgroup-per-frame kernel (default) and on the ten launches it replaces (VTD_PP_FUSED=0): both must
-    match the oracle bit for bit, so they match one another."""
+    """Every case runs on the ten launches (default) and on the one-workgroup-per-frame kernel that can replace them (VTD_PP_FUSED=1):
+    both must match the oracle bit for bit, so they match one another."""
     monkeypatch.setenv("VTD_PP_FUSED", "1" if request.param == "frame-kernel" else "0")
 
 

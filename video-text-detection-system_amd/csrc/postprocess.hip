@@ -466,7 +466,8 @@ __global__ void pp_row_extents(const PostWs ws) {
 // drop the CU's L1: a word a stage read (or initialised) with a plain access and another wave then changed by an L2 atomic must not be
 // served from that L1 to the next stage, so every stage change is barrier -> one wave invalidates the L1 (agent-scope acquire) ->
 // barrier.  Why: the ten launches were 0.3 ms of summed in-situ kernel time per batch, each spread thin over every CU the detector's and
-// the recogniser's wide kernels want (round-3 review); here a batch's post-process holds 16 waves on n CUs, once.
+// the recogniser's wide kernels want (round-3 review); here a batch's post-process holds 16 waves on n CUs, once.  An OPTION
+// (VTD_PP_FUSED=1), not the default: it measured 1 % slower end to end (vtd_postproc_run below).
 __device__ __forceinline__ void pp_stage_sync() {
     __syncthreads();   // every wave's stores and atomics of the stage have been issued and acknowledged (s_waitcnt vmcnt(0) in front of the barrier)
     if (threadIdx.x < 64) {
@@ -864,10 +865,13 @@ int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32
     const int64_t words = (int64_t)n * ws.h * ws.wpr;
     const int iblocks = (int)std::min<int64_t>(((int64_t)n * ws.h + 3) / 4, 256 * 16);  // one wave per row
     const int wblocks = (int)std::min<int64_t>((words + 255) / 256, 256 * 16);      // one thread per word
-    // one workgroup per frame for everything up to the row tables (VTD_PP_FUSED=0: the ten launches it replaces; bit-identical results:
-    // tests/test_gpu_postprocess.py runs both)
+    // VTD_PP_FUSED=1: one workgroup per frame for everything up to the row tables instead of the ten launches (bit-identical results:
+    // tests/test_gpu_postprocess.py runs both).  Measured on one box, three alternating repetitions of the default bench line
+    // (tools/gpu_pp.sh): 12.90-12.97 k frames/s sustained against 13.02-13.08 k with the ten launches, the head entry's in-situ time equal
+    // within the spread (465-476 against 472-483 us) -- the frame kernel holds its CUs for 650 us per batch where the chain takes 300, and
+    // the thin launches were not what stretches the wide kernels.  The ten launches stay the default.
     const char* fe = getenv("VTD_PP_FUSED");
-    if (!(fe && fe[0] == '0')) {
+    if (fe && fe[0] == '1') {
         hipLaunchKernelGGL(pp_frame_kernel, dim3(n), dim3(SCAN_THREADS), 0, s, ws);
     } else {
         hipLaunchKernelGGL(pp_init, dim3(iblocks), dim3(256), 0, s, ws);
