@@ -101,17 +101,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     // GEMM row m -> output pixel.  Plain: raster order over (image, oy, ox).  Pooled (pool_log2 = log2 of the window size: a 2 x pool_pw
     // max-pool follows the conv's ReLU and is taken in the epilogue): WINDOW-major -- the rows of one pooling window are consecutive, so
     // they sit in neighbouring lanes of one accumulator fragment whatever the tile shape: m = window index * window size + (dy * pool_pw + dx)
+    // (the two divisions are multiplications by ceil(2^40 / d) whenever the launcher found them exact for this launch -- magic_ok: an
+    // integer division is ~35 vector instructions on this ISA, and a short-K tile (9 K-steps: the layer-2 entry, CRNN conv2, the 1x1
+    // laterals) has only 72 MFMAs per wave to hide its A_INST x 2 of them behind: SQ counters had conv_igemm<128,64,2,2,2> at 6.9 vector
+    // instructions per MFMA)
+    auto div_rows = [&](int v, int d_howo, int& q, int& r) {
+        q = p.magic_ok ? (int)(((uint64_t)(uint32_t)v * p.magic_howo) >> 40) : v / d_howo;
+        r = v - q * d_howo;
+    };
+    auto div_cols = [&](int v, int d_wo, int& q, int& r) {
+        q = p.magic_ok ? (int)(((uint64_t)(uint32_t)v * p.magic_wo) >> 40) : v / d_wo;
+        r = v - q * d_wo;
+    };
     auto row_pixel = [&](int m, int& img, int& oy, int& ox) {
         if (p.pool_log2 == 0) {
-            img = m / howo;
-            const int rem = m - img * howo;
-            oy = rem / p.wo;
-            ox = rem - oy * p.wo;
+            int rem;
+            div_rows(m, howo, img, rem);
+            div_cols(rem, p.wo, oy, ox);
         } else {
             const int widx = m >> p.pool_log2, sub = m & ((1 << p.pool_log2) - 1);
-            img = widx / p.pool_hqwq;
-            const int rem = widx - img * p.pool_hqwq;
-            const int qy = rem / p.pool_wq, qx = rem - qy * p.pool_wq;
+            int rem, qy, qx;
+            div_rows(widx, p.pool_hqwq, img, rem);
+            div_cols(rem, p.pool_wq, qy, qx);
             oy = 2 * qy + (p.pool_pw == 2 ? sub >> 1 : sub);
             ox = p.pool_pw == 2 ? 2 * qx + (sub & 1) : qx;
         }
@@ -799,11 +810,15 @@ int vtd_launch_conv(const ConvParams& p_in, int cfg, hipStream_t stream) {
         const uint64_t wo_e = pooled ? (uint64_t)p.pool_wq : (uint64_t)p.wo;
         const uint64_t howo = pooled ? (uint64_t)p.pool_hqwq : (uint64_t)p.ho * (uint64_t)p.wo;
         p.epi_direct = 0;
-        if (allow && epi_direct_eligible(p)) {
-            p.epi_direct = 1;
+        // m -> (image, row, column) by multiplication: exact for every m < M when M x divisor < 2^40 (the error of ceil(2^40 / d) is
+        // below d / 2^40 per unit of m).  Used by the loader of every launch that qualifies, and by the register epilogue.
+        p.magic_ok = 0;
+        if (!p.plist && (uint64_t)p.M * howo < (1ull << 40) && p.M > 0) {
+            p.magic_ok = 1;
             p.magic_wo = ((1ull << 40) + wo_e - 1) / wo_e;
             p.magic_howo = ((1ull << 40) + howo - 1) / howo;
         }
+        if (allow && epi_direct_eligible(p) && p.magic_ok) p.epi_direct = 1;
     }
     switch (cfg) {
         case 0: return launch_plain<256, 128, 4, 2, 3>(p, stream);

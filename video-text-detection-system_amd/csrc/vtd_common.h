@@ -72,7 +72,8 @@ struct ConvParams {
     // max-pool 2 x pool_pw (stride = window) behind the ReLU, fused into the register epilogue: pool_pw = 1 or 2 (0: none); `out` is then
     // the POOLED tensor.  pool_log2 / pool_wq / pool_hqwq are derived by vtd_launch_conv (window size log2, pooled width, pooled pixels per image)
     int pool_pw, pool_log2, pool_wq, pool_hqwq;
-    uint64_t magic_wo, magic_howo;  // ceil(2^40 / wo), ceil(2^40 / (ho * wo)) for it
+    uint64_t magic_wo, magic_howo;  // ceil(2^40 / wo), ceil(2^40 / (ho * wo)) for it (pooled: of the pooled map)
+    int magic_ok;          // set by vtd_launch_conv: the two multiplications are exact for every row of this launch (loader + epilogue)
     // ---- classed dual-source mode (fused FPN-top + head entry, see vtd_api.cpp: compose_head_entry)
     const uint32_t* plist;   // per-image pixel list, tile-aligned: y | x << 16, 0xffffffff = padding row
     const int* tile_combo;   // per tile in execution order: weight class | pixel-list chunk << 8
