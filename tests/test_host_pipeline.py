@@ -257,6 +257,49 @@ def test_failing_first_group_of_a_mixed_batch_yields_every_frame_once(pipe):
         run(8, fail_in)   # the last group fails
 
 
+def test_swallowed_errors_are_counted(pipe):
+    """The reference's error convention turns a failing detector batch into empty detections and a failing recogniser into empty strings
+    (log and go on).  A caller that must not read such a run as a result -- bench.py, which once posted 662 frames/s for a recogniser that
+    failed every pass -- finds the count in ``error_counts``."""
+    class _Eng:
+        max_batch = 8
+
+    class _Model:
+        def engine(self):
+            return _Eng()
+
+    pipe.__dict__.pop("_inflight", None)
+    pipe.__dict__.pop("error_counts", None)
+    pipe.detector.model = _Model()
+    pipe._upload = object()
+    pipe._bind_device = lambda: None
+    pipe._stage = lambda chunk: (list(chunk), None)
+    calls = {"n": 0}
+
+    def detect(batch):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("enqueue failed")
+        return {"batch": batch}
+
+    pipe.submit_detection = detect
+    pipe._try_recognition = lambda job: job.setdefault("rec", True)
+
+    def collect(job, info):
+        if int(job["batch"][0][0, 0, 0]) == 3:
+            raise RuntimeError("collection failed")
+        return [{"frame_number": n, "timestamp": t, "detections": ["box"]} for n, t in info]
+
+    pipe.collect = collect
+    out = []
+    for k in range(5):
+        out += pipe._pipeline_push([np.full((4, 6, 3), k, np.uint8)], [(k, 0.0)])
+    out += pipe._pipeline_drain()
+    assert [r["frame_number"] for r in out] == list(range(5))
+    assert [bool(r["detections"]) for r in out] == [True, False, True, False, True]
+    assert pipe.error_counts == {"detection": 1, "collection": 1}
+
+
 def test_host_frames_enter_the_detector_one_interval_after_their_copy(pipe, monkeypatch):
     """Host frames are staged (pinned buffer + copy on the upload stream) when pushed and enter the detector when the NEXT job is
     pushed, so the detector never waits for its own batch's copy; every stage advances one job per push, results stay whole and in
