@@ -432,7 +432,10 @@ def main():
         detector_roofline = roofline
         cross = None
         if calls:
-            bytes_total = rows * spec.enc_tokens * spec.dec_hidden * 2 * 2
+            # bytes every live row's launch reads: keys + values of the layer ([T][D] fp16 each), or -- cross-attention on the raw encoder
+            # states (engine.xattn) -- the encoder states themselves ([T][C] fp16, once)
+            per_row = spec.enc_tokens * (spec.enc_hidden * 2 if getattr(teng, "xattn", False) else spec.dec_hidden * 2 * 2)
+            bytes_total = rows * per_row
             achieved = bytes_total / (ms * 1e-3) / 1e9
             traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")   # its largest launch: rows stated in traffic_detail
             cross = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",

@@ -504,6 +504,9 @@ class TrOCREngine(_Tunable):
             # one encoder-output slot unless the overlapped order (two passes in flight) or a caller asks for the second one
             want_slots = slots or (2 if os.environ.get("VTD_TROCR_OVERLAP", "0") == "1" else 1)
             _native.check(self.lib.vtd_trocr_set_option(h, b"slots", int(want_slots)), "vtd_trocr_set_option(slots)")
+            # decoder cross-attention on the raw encoder states (csrc/trocr_xattn.hip) instead of per-layer key / value projections
+            self.xattn = os.environ.get("VTD_TROCR_XATTN", "0") == "1"
+            _native.check(self.lib.vtd_trocr_set_option(h, b"xattn", int(self.xattn)), "vtd_trocr_set_option(xattn)")
             for key, value in state_dict.items():
                 arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
                 _native.check(self.lib.vtd_trocr_set_tensor(h, hf4_key(key).encode(), arr.ctypes.data, arr.size), f"vtd_trocr_set_tensor({key})")
