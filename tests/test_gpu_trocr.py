@@ -381,3 +381,45 @@ def test_dense_gemm_encoder_pass_matches_goldens_and_repeats_bitwise(base, golde
         with eng.lock:
             eng.encode_crops(dev, boxes)
         assert np.array_equal(eng.read_tap("encoder", len(crops)), enc_dg), var
+
+
+def test_cross_attention_on_the_encoder_states_equals_the_key_value_form(tiny, base, golden_dir):
+    """csrc/trocr_xattn.hip attends over the raw encoder states with a composed query (q_h Wk_h) and projects the attended state
+    (Wv_h) afterwards -- algebraically the reference's attention over K = E Wk^T + bk, V = E Wv^T + bv (q . bk is the same for every
+    token and leaves the softmax; the probabilities sum to 1, so bv passes through).  Both forms of one checkpoint: teacher-forced
+    logits within the tolerance the goldens are held to, identical greedy ids on the margin-selected golden crops, the other form's
+    encoder states untouched, bit-repeatable."""
+    from vtd_amd.engine import DeviceFrames, TrOCREngine, trim_generated
+    g = np.load(os.path.join(golden_dir, "trocr_tiny.npz"))
+    want = g["logits"]
+    pair = min(float(np.abs(want[i, 0] - want[j, 0]).max()) for i in range(12) for j in range(i))
+    for (eng, sd), spec in ((tiny, TINY), (base, BASE_PRINTED)):
+        other = TrOCREngine(spec, sd, max_crops=16, xattn=not eng.xattn)
+        try:
+            assert other.xattn != eng.xattn
+            if spec is TINY:
+                x = torch.stack([otrocr.preprocess(synth.glyph_crop(600 + i), TINY) for i in range(12)])
+                forced = g["ids"]
+            else:
+                x = torch.stack([otrocr.preprocess(synth.glyph_crop(960 + i), BASE_PRINTED) for i in range(7)])
+                forced = eng.generate_pixels(x)[0].numpy()[:, :8]
+            ids_a, lg_a = eng.generate_pixels(x, forced=forced, want_logits=True, max_length=forced.shape[1] + 1)
+            enc_a = eng.read_tap("encoder", len(x))
+            ids_b, lg_b = other.generate_pixels(x, forced=forced, want_logits=True, max_length=forced.shape[1] + 1)
+            enc_b = other.read_tap("encoder", len(x))
+            assert np.array_equal(enc_a, enc_b)
+            steps = forced.shape[1]
+            live = (forced[:, :-1] != spec.pad_token_id) | (np.arange(steps - 1)[None] == 0)
+            a, b = lg_a.numpy()[:, :steps - 1], lg_b.numpy()[:, :steps - 1]
+            err = float(np.abs(a - b)[live].max())
+            print(spec.image_size, "logit max abs difference between the two forms", err)
+            assert err <= (pair / 20 if spec is TINY else 0.015 / 5)
+            _, lg_b2 = other.generate_pixels(x, forced=forced, want_logits=True, max_length=forced.shape[1] + 1)
+            assert np.array_equal(lg_b.numpy(), lg_b2.numpy())
+            if spec is BASE_PRINTED:
+                man = json.load(open(os.path.join(golden_dir, "trocr_manifest.json")))["base"]["rows"]
+                frames, boxes = _crops_in_frames([synth.glyph_crop(r["seed"]) for r in man])
+                got = trim_generated(other.generate_crops(DeviceFrames(frames), boxes), BASE_PRINTED)
+                assert got == [r["ids"] for r in man]
+        finally:
+            other.close()

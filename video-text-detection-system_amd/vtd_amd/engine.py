@@ -486,7 +486,7 @@ class TrOCREngine(_Tunable):
 
     _kind = "trocr"
 
-    def __init__(self, spec, state_dict, max_crops=None, slots=None):
+    def __init__(self, spec, state_dict, max_crops=None, slots=None, xattn=None):
         from .trocr_spec import hf4_key
         self.lib = _native.require()
         self.spec = spec
@@ -505,7 +505,7 @@ class TrOCREngine(_Tunable):
             want_slots = slots or (2 if os.environ.get("VTD_TROCR_OVERLAP", "0") == "1" else 1)
             _native.check(self.lib.vtd_trocr_set_option(h, b"slots", int(want_slots)), "vtd_trocr_set_option(slots)")
             # decoder cross-attention on the raw encoder states (csrc/trocr_xattn.hip) instead of per-layer key / value projections
-            self.xattn = os.environ.get("VTD_TROCR_XATTN", "0") == "1"
+            self.xattn = (os.environ.get("VTD_TROCR_XATTN", "0") == "1") if xattn is None else bool(xattn)
             _native.check(self.lib.vtd_trocr_set_option(h, b"xattn", int(self.xattn)), "vtd_trocr_set_option(xattn)")
             for key, value in state_dict.items():
                 arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
