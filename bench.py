@@ -423,8 +423,8 @@ def main():
         # The Transformer line is bound by its recogniser.  Its dominant kernel BY SHARE OF KERNEL TIME is the encoder pass's dense GEMM
         # (profiles/r03_trocr_pipeline_kernel_stats.csv: dense_gemm_kernel 33 % against 15.5 % for the decoder's cross-attention), an
         # MFMA-bound launch: `roofline` is that kernel's, FLOPs executed (2 M N K per launch) / its HIP-event time on the stream it is
-        # launched on, inside the timed region.  The decoder's largest launch, the HBM-bound cross-attention (every live row's encoder keys /
-        # values read once per layer and step), is kept as a secondary record.
+        # launched on, inside the timed region.  The decoder's largest launch, the HBM-bound cross-attention (every live row's encoder states --
+        # or, in the reference's form, its keys and values -- read once per layer and step), is kept as a secondary record.
         ms, calls, rows = teng.profile()
         gms, gcalls, gflops = teng.gemm_profile()
         teng.set_profiling(0)
@@ -434,25 +434,31 @@ def main():
         if calls:
             # bytes every live row's launch reads: keys + values of the layer ([T][D] fp16 each), or -- cross-attention on the raw encoder
             # states (engine.xattn) -- the encoder states themselves ([T][C] fp16, once)
-            per_row = spec.enc_tokens * (spec.enc_hidden * 2 if getattr(teng, "xattn", False) else spec.dec_hidden * 2 * 2)
+            xattn = bool(getattr(teng, "xattn", False))
+            per_row = spec.enc_tokens * (spec.enc_hidden * 2 if xattn else spec.dec_hidden * 2 * 2)
             bytes_total = rows * per_row
             achieved = bytes_total / (ms * 1e-3) / 1e9
-            traffic, traffic_detail, traffic_error = lookup_traffic("dec_cross_attn")   # its largest launch: rows stated in traffic_detail
-            cross = {"bound": "hbm", "kernel": "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step",
+            traffic, traffic_detail, traffic_error = lookup_traffic("dec_xattn" if xattn else "dec_cross_attn")   # its largest launch: rows stated in traffic_detail
+            cross = {"bound": "hbm", "kernel": ("dec_xattn_kernel<24> (decoder cross-attention on the encoder states, trocr_xattn.hip), layer 0 of every step" if xattn else
+                                                "dec_attn_kernel<false, 4, 10> (decoder cross-attention, trocr_decode.hip), layer 0 of every step"),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (read + written)", "traffic_detail": traffic_detail,
                      "launches": calls, "avg_launch_us": round(ms / calls * 1e3, 2), "avg_live_rows_per_launch": round(rows / calls, 1),
                      "algorithmic_bytes_per_launch": int(bytes_total / calls),
-                     "note": "algorithmic bytes = live rows x encoder tokens (577) x d_model (1024) x 2 B x (K + V): every byte is read once per "
-                             "launch; rows that have emitted </s> are not read (the live list shrinks from ~272 to a handful over a batch), so "
+                     "note": ("algorithmic bytes = live rows x encoder tokens (577) x encoder width (768) x 2 B: the row's encoder states, read once per "
+                              "launch (the same states for all 12 layers of a step: below ~280 live rows they stay in the 256 MB Infinity Cache, so "
+                              "short launches can exceed the HBM rate); " if xattn else
+                              "algorithmic bytes = live rows x encoder tokens (577) x d_model (1024) x 2 B x (K + V): every byte is read once per "
+                              "launch; ") +
+                             "rows that have emitted </s> are not read (the live list shrinks from ~1100 to a handful over a pass), so "
                              "late launches are latency-bound, not bandwidth-bound; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)"}
             if traffic_error:
                 cross["traffic_error"] = traffic_error
                 print("bench.py: " + traffic_error, file=sys.stderr)
         if gcalls:
             achieved = gflops / (gms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "dense_gemm_kernel<false, 16> / <true, 1> (dense_gemm.hip): the encoder pass's dense layers and the "
-                                                   "cross-attention key / value projections",
+            roofline = {"bound": "mfma", "kernel": "dense_gemm_kernel<false, 16> / <true, 1> (dense_gemm.hip): the encoder pass's dense layers" +
+                                                   ("" if getattr(teng, "xattn", False) else " and the cross-attention key / value projections"),
                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "launches": gcalls, "avg_launch_us": round(gms / gcalls * 1e3, 2),
                         "executed_gflop_per_launch": round(gflops / gcalls / 1e9, 2),
@@ -559,7 +565,7 @@ def read_sclk_mhz():
 # launch-slot description (vtd_api.cpp: vtd_detector_get_profile) -> device kernel symbol of exactly that variant
 KERNEL_SYMBOLS = (("head_entry_pair", "head_entry_pair_kernel("), ("head_entry_half", "head_entry_half_kernel<false>("),
                   ("head_entry_halo256", "head_entry_halo256_kernel<false>("), ("head_entry_halo ", "head_entry_halo_kernel<"),
-                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 4"))
+                  ("classed", "true>("), ("dec_cross_attn", "dec_attn_kernel<false, 4"), ("dec_xattn", "dec_xattn_kernel<24>("))
 
 
 def lookup_traffic(launch_name, profiles_dir=None):
@@ -592,6 +598,11 @@ def lookup_traffic(launch_name, profiles_dir=None):
         v = pmc[key]
         rows_ = int(key.rsplit("grid=", 1)[1]) // (16 * 256)
         extra = {"live_rows_of_that_launch": rows_, "algorithmic_bytes_of_that_launch": rows_ * 577 * 1024 * 2 * 2}
+    if "dec_xattn" in symbol:   # one 768-thread workgroup per live row; the row's encoder states [577][768] fp16 read once
+        key = max((k for k, h in pmc.items() if symbol in k and h.get("launches", 0) >= 3), key=lambda k: int(k.rsplit("grid=", 1)[1]))
+        v = pmc[key]
+        rows_ = int(key.rsplit("grid=", 1)[1]) // 768
+        extra = {"live_rows_of_that_launch": rows_, "algorithmic_bytes_of_that_launch": rows_ * 577 * 768 * 2}
     rd, wr = v["hbm_read_MB_corrected_x2"], v["hbm_write_MB"]
     detail = {**extra, "hbm_read_MB": round(rd, 2), "hbm_write_MB": round(wr, 2), "kernel_symbol": symbol,
               "source": "profiles/" + os.path.basename(pmc_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median over launches, "

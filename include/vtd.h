@@ -184,10 +184,19 @@ typedef struct vtd_trocr_config {
 } vtd_trocr_config;
 int vtd_trocr_create(const vtd_trocr_config* cfg, int max_crops, vtd_trocr** out);
 void vtd_trocr_destroy(vtd_trocr* t);
-/* Build options, before finalize.  "slots" (1 or 2, default 1): encoder-output slots (cross-attention keys / values of all decoder
- * layers, 28 MB per crop each).  With 2, vtd_trocr_encode_*_slot(1) may run while slot 0 still waits for or runs its decode (events
- * inside the handle order the passes); the *_slot entry points reject slot indices >= the configured count. */
+/* Build options, before finalize.
+ * "slots" (1 or 2, default 1): encoder-output slots.  With 2, vtd_trocr_encode_*_slot(1) may run while slot 0 still waits for or runs its
+ * decode (events inside the handle order the passes); the *_slot entry points reject slot indices >= the configured count.
+ * "xattn" (default 1): the form of the decoder's cross-attention (TrOCRAttention with encoder_hidden_states, reached from
+ * text_recognizer.py:58).  0 -- as the reference computes it: the encoder pass projects the encoder states E to keys and values per decoder
+ * layer (K = E Wk^T + bk, V = E Wv^T + bv; 28 MB per crop and slot) and every decode step reads both.  1 -- the same attention with the two
+ * linear projections moved across it: scores = (q_h Wk_h) . E[t] (the q . bk term is the same for every token and leaves the softmax),
+ * context = (sum_t P[t] E[t]) Wv_h^T + bv (the probabilities sum to 1); the slot holds E itself (0.89 MB per crop), a decode step reads 0.89
+ * instead of 2.36 MB per live row and layer, the encoder pass has 24 projections less.  Results agree within the tolerances the goldens are
+ * held to and greedy ids are identical on them (tests/test_gpu_trocr.py).  Encoders wider than 768 channels or with more than 16 decoder
+ * heads keep form 0 (vtd_trocr_get_option tells which one runs after finalize); 2 -- form 1 or -1106 at finalize. */
 int vtd_trocr_set_option(vtd_trocr* t, const char* name, int value);
+int vtd_trocr_get_option(const vtd_trocr* t, const char* name, int* value);
 /* One tensor of VisionEncoderDecoderModel.state_dict() (text_recognizer.py:42): "encoder.embeddings.*",
  * "encoder.encoder.layer.N.*", "encoder.layernorm.*", "decoder.model.decoder.*", "decoder.output_projection.weight" (optional: tied to
  * embed_tokens when absent); "encoder.pooler.*" is accepted and ignored.  float32, PyTorch memory order. */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vtd_stream_create_masked": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_stream_destroy": (C.c_int, [C.c_void_p]),
     "vtd_trocr_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "vtd_trocr_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "vtd_trocr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vtd_trocr_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "vtd_trocr_get_gemm_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p]),

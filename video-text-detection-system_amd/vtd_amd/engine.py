@@ -504,9 +504,10 @@ class TrOCREngine(_Tunable):
             # one encoder-output slot unless the overlapped order (two passes in flight) or a caller asks for the second one
             want_slots = slots or (2 if os.environ.get("VTD_TROCR_OVERLAP", "0") == "1" else 1)
             _native.check(self.lib.vtd_trocr_set_option(h, b"slots", int(want_slots)), "vtd_trocr_set_option(slots)")
-            # decoder cross-attention on the raw encoder states (csrc/trocr_xattn.hip) instead of per-layer key / value projections
-            self.xattn = (os.environ.get("VTD_TROCR_XATTN", "0") == "1") if xattn is None else bool(xattn)
-            _native.check(self.lib.vtd_trocr_set_option(h, b"xattn", int(self.xattn)), "vtd_trocr_set_option(xattn)")
+            # decoder cross-attention on the raw encoder states (csrc/trocr_xattn.hip; include/vtd.h option "xattn") unless asked for the
+            # reference's per-layer key / value projections: xattn=False, or VTD_TROCR_XATTN=0
+            want_xattn = (os.environ.get("VTD_TROCR_XATTN", "1") != "0") if xattn is None else bool(xattn)
+            _native.check(self.lib.vtd_trocr_set_option(h, b"xattn", int(want_xattn)), "vtd_trocr_set_option(xattn)")
             for key, value in state_dict.items():
                 arr = np.ascontiguousarray(value.detach().cpu().float().numpy())
                 _native.check(self.lib.vtd_trocr_set_tensor(h, hf4_key(key).encode(), arr.ctypes.data, arr.size), f"vtd_trocr_set_tensor({key})")
@@ -518,6 +519,9 @@ class TrOCREngine(_Tunable):
         self.tokens = int(self.lib.vtd_trocr_encoder_tokens(h))
         self.logits_stride = int(self.lib.vtd_trocr_logits_stride(h))
         self.slots = int(self.lib.vtd_trocr_num_slots(h))
+        form = C.c_int()
+        _native.check(self.lib.vtd_trocr_get_option(h, b"xattn", C.byref(form)), "vtd_trocr_get_option(xattn)")
+        self.xattn = bool(form.value)   # the form that runs (a geometry the kernel does not cover keeps the key / value form)
         self._next_slot = 0
         self._queue = []          # tickets whose crops are not staged yet (submit_crops / finish)
         self._passes = []         # encoded passes that wait for their decode, oldest first
