@@ -18,6 +18,7 @@
 //    caches / ids / encoder keys by crop = active[j]).  The live count goes to device memory (exact, read by every kernel) and to
 //    pinned host memory (read by the host two steps late as an upper bound for the launch geometry and as the stop test).
 #include <cmath>
+#include <cstdlib>
 #include "vtd_common.h"
 
 namespace {
@@ -478,7 +479,9 @@ int vtd_launch_dec_gemm(const half_t* A, int lda, const half_t* W, const float* 
     if (M <= 0 || N <= 0 || K <= 0 || ksplit <= 0 || (K % (ksplit * 32)) || !n_rows_dev) return -2501;
     if (ksplit > 1 && !(flags & DG_PARTIAL)) return -2502;
     DecGemmParams p{A, W, bias, out, slab_stride, n_rows_dev, lda, ldc, M, N, K, ksplit, flags};
-    if (wide) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile
+    static const int tall = [] { const char* e = std::getenv("VTD_DEC_GEMM_TALL"); return e ? atoi(e) : 256; }();
+    if (wide || M >= tall) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile, and
+        // any projection of a tall live list (half the operand re-reads of the 64 x 32 tile; same K order per output, same result)
         const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
         hipLaunchKernelGGL((dec_gemm_kernel<4, 4>), grid, dim3(256), 0, s, p);
     } else if (M <= 16) {   // the tail of a decode (a handful of live rows): 16-row tiles, all of a wave's K range in one batch of loads.

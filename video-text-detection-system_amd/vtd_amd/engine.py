@@ -490,8 +490,8 @@ class TrOCREngine(_Tunable):
         from .trocr_spec import hf4_key
         self.lib = _native.require()
         self.spec = spec
-        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~47 MB of HBM each: one
-                                                                                            # encoder-output slot of 28 MB per row + workspaces; 75 MB with two slots)
+        self.max_crops = max_crops or int(os.environ.get("VTD_TROCR_MAX_CROPS", "256"))   # rows per encoder pass / decode (~20 MB of HBM each:
+                                                                                            # workspaces + caches + a 0.89 MB slot; 47 MB with the 28 MB slot of xattn=False)
         self.lock = threading.Lock()
         cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
                                   int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
