@@ -64,11 +64,12 @@ def test_roofline_traffic_lookup_covers_the_shipped_dominant_kernel_and_fails_lo
 
 def test_roofline_traffic_lookup_for_the_transformer_line():
     """The Transformer lines name the decoder's cross-attention; its launches shrink with the live rows, so the lookup cites the LARGEST
-    measured grid together with its row count -- and that figure must agree with the algorithmic bytes of the same launch (every key /
-    value byte of a live row is read exactly once per layer and step)."""
+    measured grid together with its row count -- and that figure must agree with the algorithmic bytes of the same launch: every byte of a
+    live row's encoder states (default form) or keys / values (the reference's form) is read exactly once per layer and step."""
     import bench
-    traffic, detail, err = bench.lookup_traffic("dec_cross_attn")
-    assert err is None and detail["kernel_symbol"].startswith("dec_attn_kernel<false")
-    rows = detail["live_rows_of_that_launch"]
-    assert rows >= 256
-    assert 0.95 <= traffic / detail["algorithmic_bytes_of_that_launch"] <= 1.10
+    for launch, symbol in (("dec_xattn", "dec_xattn_kernel<24>"), ("dec_cross_attn", "dec_attn_kernel<false")):
+        traffic, detail, err = bench.lookup_traffic(launch)
+        assert err is None and detail["kernel_symbol"].startswith(symbol)
+        rows = detail["live_rows_of_that_launch"]
+        assert rows >= 256
+        assert 0.95 <= traffic / detail["algorithmic_bytes_of_that_launch"] <= 1.10, (launch, rows, traffic, detail)
