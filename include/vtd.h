@@ -117,6 +117,10 @@ void vtd_postproc_destroy(vtd_postproc* pp);
  * discovery); counts_dev[i] = number of detections of frame i before truncation to max_out. */
 int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
                      float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream);
+/* Copy `bytes` of device memory to PINNED host memory (hipHostMalloc / torch pin_memory; both pointers 16-byte aligned) with a kernel on
+ * `stream` instead of hipMemcpyAsync -- a launch never makes the host wait for the GPU, which the asynchronous copy of the detection records
+ * was seen to do once per drained pipeline.  Order the host behind it with an event on `stream`.  Fails (HIP error) for pageable memory. */
+int vtd_copy_to_pinned_host(const void* src_dev, void* dst_pinned_host, int64_t bytes, vtd_stream stream);
 
 /* ---- training loss, forward only (app/ml/training/trainer.py:48-56 training_step, :66-71 validation_step, :130-142 DiceLoss) --
  * total = nn.BCELoss()(probability, probability_map) + nn.BCELoss()(threshold, threshold_map) + DiceLoss()(probability,

@@ -194,3 +194,33 @@ def test_failing_batch_degrades_to_empty_detections(pipe32, tmp_path, caplog):
         assert [d["bbox"] for d in fr["detections"]] == [d["bbox"] for d in ok["detections"]]
         assert all(d["text"] == "" and d["recognition_confidence"] == 0.0 for d in fr["detections"])
     assert real_boxes is not None
+
+
+def test_kernel_copy_to_pinned_host_and_its_fallback(hip):
+    """include/vtd.h vtd_copy_to_pinned_host: the result records travel to pinned host memory by a copy kernel (an asynchronous memcpy
+    there was seen to block the host once per drained pipeline).  Whole 16-byte pieces and a tail, on a side stream behind an event;
+    pageable memory is refused, and the Python helper then takes the plain asynchronous copy."""
+    from vtd_amd.engine import copy_to_pinned
+    g = torch.Generator().manual_seed(3)
+    side = torch.cuda.Stream()
+    for numel in (4, 32, 32 * 64 * 16, 1001, 7):
+        src = torch.randint(-2 ** 31, 2 ** 31 - 1, (numel,), dtype=torch.int32, generator=g).cuda()
+        dst = torch.zeros(numel, dtype=torch.int32).pin_memory()
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            if numel * 4 >= 16:
+                assert hip.vtd_copy_to_pinned_host(src.data_ptr(), dst.data_ptr(), numel * 4, side.cuda_stream) == 0
+            else:
+                copy_to_pinned(dst, src)
+            done = torch.cuda.Event()
+            done.record()
+        done.synchronize()
+        assert torch.equal(dst, src.cpu()), numel
+    src = torch.arange(64, dtype=torch.int32).cuda()
+    pageable = torch.zeros(64, dtype=torch.int32)
+    assert hip.vtd_copy_to_pinned_host(src.data_ptr(), pageable.data_ptr(), 256, torch.cuda.current_stream().cuda_stream) != 0
+    copy_to_pinned(pageable, src)
+    torch.cuda.synchronize()
+    assert torch.equal(pageable, src.cpu())

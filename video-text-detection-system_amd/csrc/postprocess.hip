@@ -839,6 +839,32 @@ void vtd_postproc_destroy(vtd_postproc* pp) {
     delete pp;
 }
 
+// Device -> pinned host copy as a kernel (16-byte stores straight into the mapped host buffer).  Why not hipMemcpyAsync: on the
+// post-process side stream, behind a cross-stream event wait, the third device-to-host copy after the device had been idle was seen to
+// BLOCK the host until the copy could run -- 5.6 ms once per drained pipeline, i.e. once per 20-step bench window (bench.py
+// VTD_BENCH_STAMPS=2 + line timers in TextDetector.submit_batch).  A kernel launch never waits for the GPU.  The caller orders the host
+// behind the copy with an event on `stream`, as it did for the asynchronous copy.
+namespace {
+__global__ __launch_bounds__(256) void pp_copy_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                              const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i < tail) dst_tail[i] = src_tail[i];
+}
+}  // namespace
+
+int vtd_copy_to_pinned_host(const void* src_dev, void* dst_pinned_host, int64_t bytes, vtd_stream stream) {
+    if (!src_dev || !dst_pinned_host || bytes <= 0 || (((uintptr_t)src_dev | (uintptr_t)dst_pinned_host) & 15)) return -1100;
+    void* mapped = nullptr;
+    VTD_HIP_CHECK(hipHostGetDevicePointer(&mapped, dst_pinned_host, 0));   // fails for memory that is not pinned: the caller falls back
+    const int64_t n16 = bytes >> 4;
+    const int tail = (int)(bytes & 15);
+    const int64_t blocks = std::max<int64_t>((std::max<int64_t>(n16, tail) + 255) / 256, 1);
+    hipLaunchKernelGGL(pp_copy_to_host_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)mapped, n16,
+                       (const uint8_t*)src_dev + (n16 << 4), (uint8_t*)mapped + (n16 << 4), tail);
+    return -(int)hipGetLastError();
+}
+
 int vtd_postproc_run(vtd_postproc* pp, const float* prob_dev, int n, const int32_t* orig_w_host, const int32_t* orig_h_host,
                      float threshold, vtd_detection* out_dev, int32_t* counts_dev, vtd_stream stream) {
     if (!pp || !prob_dev || !orig_w_host || !orig_h_host || !out_dev || !counts_dev) return -1100;

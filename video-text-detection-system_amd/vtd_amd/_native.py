@@ -57,6 +57,7 @@ SIGNATURES = {
     "vtd_detector_tuning_measured": (C.c_int, [C.c_void_p]),
     "vtd_postproc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "vtd_postproc_destroy": (None, [C.c_void_p]),
+    "vtd_copy_to_pinned_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vtd_postproc_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "vtd_recognizer_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

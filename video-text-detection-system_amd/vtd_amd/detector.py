@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .engine import PINNED, DeviceFrames, PostProcessor
+from .engine import PINNED, DeviceFrames, PostProcessor, copy_to_pinned
 from .nets import DBNet
 
 logger = logging.getLogger(__name__)
@@ -128,8 +128,8 @@ class TextDetector:
                           confidence_threshold, records, counts)
             host_rec = PINNED.take((n, pp.max_out, 16))
             host_cnt = PINNED.take((n,))
-            host_rec.copy_(records, non_blocking=True)
-            host_cnt.copy_(counts, non_blocking=True)
+            copy_to_pinned(host_rec, records)
+            copy_to_pinned(host_cnt, counts)
             ev = torch.cuda.Event()
             ev.record()
         return {"rec": host_rec, "cnt": host_cnt, "event": ev, "max_out": pp.max_out, "keep": (prob, records, counts, batch)}

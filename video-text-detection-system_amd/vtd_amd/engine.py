@@ -91,6 +91,18 @@ class PinnedPool:
 PINNED = PinnedPool()
 
 
+def copy_to_pinned(dst, src):
+    """Device tensor -> pinned host tensor on the current stream, by a copy kernel (include/vtd.h vtd_copy_to_pinned_host).  The
+    asynchronous memcpy of the detection records -- a few KB on the post-process side stream -- was seen to block the host for a whole
+    detector pass, once per drained pipeline; a launch never waits for the GPU.  Falls back to the plain
+    asynchronous copy if the buffer is not mapped."""
+    nbytes = src.numel() * src.element_size()
+    if nbytes >= 16 and dst.is_pinned() and src.is_contiguous() and dst.is_contiguous() and dst.numel() * dst.element_size() == nbytes and \
+            _native.require().vtd_copy_to_pinned_host(src.data_ptr(), dst.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream) == 0:
+        return
+    dst.copy_(src, non_blocking=True)
+
+
 class DeviceFrames:
     """A batch of equally sized uint8 BGR HWC frames resident in HBM ([n,H,W,3] cuda tensor)."""
 
@@ -397,7 +409,7 @@ class RecognizerEngine(_Tunable):
                                                          C.c_void_p(id2char_dev.data_ptr()), blank_id, 1, C.c_void_p(out.data_ptr()),
                                                          _stream_ptr()), "vtd_ctc_greedy_decode")
             host = PINNED.take((k, 2 + self.T))
-            host.copy_(out, non_blocking=True)
+            copy_to_pinned(host, out)
             ev = torch.cuda.Event()
             ev.record()
         return {"host": host, "event": ev, "keep": (host_boxes, dev_boxes, logits, out, frames)}
@@ -728,7 +740,7 @@ class TrOCREngine(_Tunable):
             with torch.cuda.stream(stream):
                 ids, _ = self._enqueue_generate(pas["rows"], pas["slot"])
                 host = PINNED.take(tuple(ids.shape))
-                host.copy_(ids, non_blocking=True)
+                copy_to_pinned(host, ids)
                 ev = torch.cuda.Event()
                 ev.record()
             pas.update(host=host, event=ev, ids=ids)
