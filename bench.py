@@ -191,12 +191,13 @@ def main():
     from vtd_amd.pipeline import VideoTextPipeline
     os.environ["VTD_MAX_BATCH"] = str(B)
     if args.recognizer == "trocr":
-        # Eight steps' crops share one recogniser pass at B <= 32 (four above): a decode step costs about the same for 300 or 2000 live rows,
-        # and the slot of a crop is 0.89 MB of encoder states (28 MB of keys / values in the reference's form, VTD_TROCR_XATTN=0: ask for
-        # fewer tickets there).  360 / 372 / 394 / 410 frames/s at 4 / 6 / 8 / 12 tickets (tools/gpu_pass_sweep.sh); results come that many
-        # steps later -- process_video returns when the whole video is done, so the reference's caller does not see the difference.
-        os.environ.setdefault("VTD_TROCR_PASS_TICKETS", "8" if B <= 32 else "4")
-        os.environ.setdefault("VTD_TROCR_MAX_CROPS", "2560")
+        # Twelve steps' crops share one recogniser pass at B <= 32 (four above): a decode step costs about the same for 300 or 3000 live
+        # rows, and the slot of a crop is 0.89 MB of encoder states (28 MB of keys / values in the reference's form, VTD_TROCR_XATTN=0: ask
+        # for fewer tickets there).  360 / 372 / 394-408 / 410-426 frames/s at 4 / 6 / 8 / 12 tickets (tools/gpu_pass_sweep.sh; a pass holds at most
+        # 4096 rows); results come that many steps later -- process_video returns when the
+        # whole video is done, so the reference's caller does not see the difference.
+        os.environ.setdefault("VTD_TROCR_PASS_TICKETS", "12" if B <= 32 else "4")
+        os.environ.setdefault("VTD_TROCR_MAX_CROPS", "3456" if B <= 32 else "2560")
         os.environ.setdefault("VTD_TROCR_SEEDED", "0")   # explicit opt-in: the architecture on synthetic weights (nothing is fetchable)
     pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 evidence visit (one box): the whole -m gpu suite, smoke, the bench lines (default, detector, upload, 1080p, Transformer lines,
-# configs[4], ResNet-50 detector), recogniser per-launch table, kernel-trace stats, PMC traffic passes (default + Transformer workloads).
+# Round-4 evidence visit (one box): the whole -m gpu suite, smoke, the bench lines (default, detector, upload, 1080p, ResNet-50 detector),
+# recogniser per-launch table, kernel-trace stats, PMC traffic passes of the default workload.  The Transformer lines: tools/gpu_evidence4b.sh.
 # Outputs under gpurun_out/ev4; tools/collect_evidence4.py copies the summaries into profiles/r04_*.
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/ev4
@@ -25,14 +25,6 @@ cut -c1-160 $out/bench_full_1080p.json
 step "fusions off (same box)"
 VTD_DETECTOR_OPTIONS=fuse_downsample=0 VTD_RECOGNIZER_OPTIONS=fuse_pools=0 VTD_TILE_HEIGHT_MODEL=0 timeout -k 10 300 python bench.py --cpu-seconds 0 --no-profile > $out/bench_full_unfused.json 2> $out/bench_full_unfused.err || { tail -5 $out/bench_full_unfused.err; exit 1; }
 cut -c1-160 $out/bench_full_unfused.json
-timeout -k 10 300 python tools/trocr_stage_bench.py > $out/trocr_stages.log 2>&1 || { tail -5 $out/trocr_stages.log; exit 1; }
-tail -3 $out/trocr_stages.log
-timeout -k 10 600 python bench.py --recognizer trocr --steps 16 --warmup 8 --cpu-seconds 0 > $out/bench_r18_trocr_b32.json 2> $out/bench_r18_trocr_b32.err || { tail -5 $out/bench_r18_trocr_b32.err; exit 1; }
-cut -c1-200 $out/bench_r18_trocr_b32.json
-VTD_TROCR_PASS_TICKETS=2 VTD_TROCR_MAX_CROPS=1024 timeout -k 10 600 python bench.py --recognizer trocr --steps 16 --warmup 8 --cpu-seconds 0 --sustain-seconds 0 > $out/bench_r18_trocr_b32_t2.json 2> $out/bench_r18_trocr_b32_t2.err || { tail -5 $out/bench_r18_trocr_b32_t2.err; exit 1; }
-cut -c1-200 $out/bench_r18_trocr_b32_t2.json
-timeout -k 10 900 python bench.py --backbone resnet50 --recognizer trocr --mixed --steps 16 --warmup 8 --cpu-seconds 12 > $out/bench_cfg4_b32.json 2> $out/bench_cfg4_b32.err || { tail -5 $out/bench_cfg4_b32.err; exit 1; }
-cut -c1-200 $out/bench_cfg4_b32.json
 timeout -k 10 300 python bench.py --backbone resnet50 --workload detector --cpu-seconds 0 --sustain-seconds 0 --layers-out $out/layers_r50.json > $out/bench_r50_det.json 2> $out/bench_r50_det.err || { tail -5 $out/bench_r50_det.err; exit 1; }
 cut -c1-160 $out/bench_r50_det.json
 step "recogniser alone per launch"
@@ -41,14 +33,9 @@ python tools/rec_layers.py $(ls $out/rec272/*kernel_trace.csv | head -1) 23 > $o
 tail -1 $out/recognizer_launch_table.txt
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -o run -- python3 $R/bench.py --cpu-seconds 0 --sustain-seconds 0 --no-profile > $R/$out/stats.log 2>&1 || { tail -5 $R/$out/stats.log; exit 1; }
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats_trocr -o run -- python3 $R/bench.py --recognizer trocr --steps 8 --warmup 4 --cpu-seconds 0 --sustain-seconds 0 --no-profile > $R/$out/stats_trocr.log 2>&1 || { tail -5 $R/$out/stats_trocr.log; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/pmc_fetch -o run -- python3 $R/bench.py --cpu-seconds 0 --sustain-seconds 0 --no-profile --steps 4 --warmup 1 > $R/$out/pmc_fetch.log 2>&1 || { tail -5 $R/$out/pmc_fetch.log; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/pmc_write -o run -- python3 $R/bench.py --cpu-seconds 0 --sustain-seconds 0 --no-profile --steps 4 --warmup 1 > $R/$out/pmc_write.log 2>&1 || { tail -5 $R/$out/pmc_write.log; exit 1; }
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/pmc_fetch_trocr -o run -- python3 $R/bench.py --recognizer trocr --cpu-seconds 0 --sustain-seconds 0 --no-profile --steps 4 --warmup 0 > $R/$out/pmc_fetch_trocr.log 2>&1 || { tail -5 $R/$out/pmc_fetch_trocr.log; exit 1; }
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/pmc_write_trocr -o run -- python3 $R/bench.py --recognizer trocr --cpu-seconds 0 --sustain-seconds 0 --no-profile --steps 4 --warmup 0 > $R/$out/pmc_write_trocr.log 2>&1 || { tail -5 $R/$out/pmc_write_trocr.log; exit 1; }
 cd $R
 python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic_per_launch.json
-python tools/pmc_summary.py $out/pmc_fetch_trocr $out/pmc_write_trocr $out/pmc_traffic_per_launch_trocr.json
 python tools/hbm_table.py $out/pmc_traffic_per_launch.json $(ls $out/stats/*kernel_trace.csv | head -1) $out/layers_det.json $out/hbm_bound_kernels.json || true
-rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_fetch_trocr $out/pmc_write_trocr $out/rec272
 ls $out | head -60

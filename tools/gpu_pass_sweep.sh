@@ -3,8 +3,8 @@
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/pass_sweep
 mkdir -p $out
-for t in ${TS:-4 6 8}; do
-  VTD_TROCR_PASS_TICKETS=$t VTD_TROCR_MAX_CROPS=$((t * 288)) timeout -k 10 500 python bench.py --recognizer trocr --steps $((4 * t)) --warmup $((2 * t)) --cpu-seconds 0 --sustain-seconds 0 > $out/t$t.json 2> $out/t$t.err || { tail -20 $out/t$t.err; exit 1; }
+for t in ${TS:-4 6 8 12}; do
+  VTD_TROCR_PASS_TICKETS=$t VTD_TROCR_MAX_CROPS=$((t * 288)) timeout -k 10 500 python bench.py --recognizer trocr --steps $((3 * t)) --warmup $((2 * t)) --cpu-seconds 0 --sustain-seconds 0 > $out/t$t.json 2> $out/t$t.err || { tail -20 $out/t$t.err; exit 1; }
   python - <<PY
 import json
 b=json.load(open("$out/t$t.json")); r=b["roofline"]; c=r.get("decoder_cross_attention") or {}
