@@ -39,3 +39,4 @@ for k, v in res.items():
 json.dump(out, open("gpurun_out/pmc_trocr/summary.json", "w"), indent=1, sort_keys=True)
 PY
 rm -rf $out/p1 $out/p2
+rm -rf gpurun_out/pmc_trocr/p1 gpurun_out/pmc_trocr/p2
