@@ -17,6 +17,11 @@ namespace {
 constexpr int PRE_TY = 16;
 constexpr int PRE_OUT = 640;
 constexpr int PRE_CHUNK = 4;  // raw input rows staged per pass
+#ifndef VTD_PRE_NT
+#define VTD_PRE_NT 640
+#endif
+constexpr int PRE_NT = VTD_PRE_NT;   // threads of the fast path's workgroup (an instrumented build may pass -DVTD_PRE_NT=256 for the A/B)
+constexpr int PRE_COLS = (PRE_OUT + PRE_NT - 1) / PRE_NT;   // output columns per thread
 
 struct PreParams {
     const uint8_t* frames;  // [n, H, W, 3]
@@ -122,8 +127,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
 //   * a thread owns fixed output columns (t, t+256, t+512) for the whole horizontal pass, so its tap tables live in
 //     registers; taps past a window's end carry zero weights (Pillow pads its tables the same way);
 //   * the vertical pass produces 4 neighbouring pixels per thread: one 16-byte LDS read per tap, one 32-byte store.
+// PRE_NT threads = one output column per thread (640): ten waves per workgroup, two workgroups per CU.  With 256 threads (three columns per
+// thread, the third on half the lanes) the waves sat parked at the chunk barriers for 63 % of their cycles (r04_pmc_sq_summary.json) with
+// only eight of them on a CU to cover for one another.
 template <int KSX, int KSY>
-__global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p) {
+__global__ __launch_bounds__(PRE_NT) void preprocess_fast_kernel(const PreParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // [max_rows][640] dwords (resampled rows) | PRE_CHUNK x [W + KSX] dwords (raw rows, widened) | 16 x (2 + KSY) ints (row taps)
     uint32_t* const rows = (uint32_t*)lds;
@@ -142,39 +150,41 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
     const int tid = threadIdx.x;
 
     // this thread's output columns and their horizontal taps
-    int xmin[3], kx[3][KSX];
+    int xmin[PRE_COLS], kx[PRE_COLS][KSX];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int ox = min(tid + 256 * s, PRE_OUT - 1);
+    for (int s = 0; s < PRE_COLS; ++s) {
+        const int ox = min(tid + PRE_NT * s, PRE_OUT - 1);
         xmin[s] = p.xb[2 * ox];
 #pragma unroll
         for (int t = 0; t < KSX; ++t) kx[s][t] = p.xk[ox * KSX + t];
     }
-    for (int i = tid; i < PRE_TY * (2 + KSY); i += 256) {
+    for (int i = tid; i < PRE_TY * (2 + KSY); i += PRE_NT) {
         const int ty = i / (2 + KSY), e = i - ty * (2 + KSY);
         const int oy = min(oy0 + ty, PRE_OUT - 1);
         ytab[i] = e < 2 ? p.yb[2 * oy + e] : p.yk[oy * KSY + (e - 2)];
     }
     // zero the KSX padding pixels behind every raw row once (read with zero weights only, but they must be defined)
-    for (int i = tid; i < PRE_CHUNK * KSX; i += 256) raw[(i / KSX) * raw_pitch + p.W + (i % KSX)] = 0u;
+    for (int i = tid; i < PRE_CHUNK * KSX; i += PRE_NT) raw[(i / KSX) * raw_pitch + p.W + (i % KSX)] = 0u;
     {   // The resampled pixel is an 8-bit level, so (v / 255 - mean) / std has 256 possible values per channel: evaluate the
         // reference's expression (two IEEE divisions, ~25 instructions) once per level instead of once per pixel.
         const float mean[3] = {0.485f, 0.456f, 0.406f};
         const float stdv[3] = {0.229f, 0.224f, 0.225f};
+        if (tid < 256) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) lut[c * 256 + tid] = (half_t)(((float)tid / 255.0f - mean[c]) / stdv[c]);
+            for (int c = 0; c < 3; ++c) lut[c * 256 + tid] = (half_t)(((float)tid / 255.0f - mean[c]) / stdv[c]);
+        }
     }
 
     const int quads = p.W >> 2;  // 4 pixels = 12 bytes = 3 dwords (W % 4 == 0 on this path)
     // raw rows travel HBM -> registers -> LDS; the registers of chunk c+1 are loaded before chunk c is resampled, so the
     // memory latency (~2 us) hides behind the horizontal taps instead of being paid once per chunk
-    constexpr int MAXIT = 8;  // PRE_CHUNK * (W / 4) / 256 <= 8  <=>  W <= 2048 (checked by the launcher)
+    constexpr int MAXIT = (PRE_CHUNK * 512 + PRE_NT - 1) / PRE_NT;  // PRE_CHUNK * (W / 4) / PRE_NT <= MAXIT  <=>  W <= 2048 (checked by the launcher)
     uint32_t stg[MAXIT][3];
     auto fetch = [&](int r0) {
         const int nr = min(PRE_CHUNK, nrows - r0);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * PRE_NT;
             if (i < nr * quads) {
                 const int rr = (int)__umulhi((unsigned)i, p.quads_magic), q = i - rr * quads;  // i / quads (exact: i * quads < 2^32)
                 const uint32_t* g = (const uint32_t*)(src + (int64_t)(y_first + r0 + rr) * row_bytes) + q * 3;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
         const int nr = min(PRE_CHUNK, nrows - r0);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * PRE_NT;
             if (i < nr * quads) {
                 const int rr = (int)__umulhi((unsigned)i, p.quads_magic), q = i - rr * quads;
                 const uint32_t d0 = stg[it][0], d1 = stg[it][1], d2 = stg[it][2];
@@ -204,8 +214,8 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
         for (int rr = 0; rr < nr; ++rr) {
             const uint32_t* row = raw + rr * raw_pitch;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int ox = tid + 256 * s;
+            for (int s = 0; s < PRE_COLS; ++s) {
+                const int ox = tid + PRE_NT * s;
                 if (ox < PRE_OUT) {
                     // 8-bit level x 22-bit coefficient (bilinear: never negative): the 24-bit multiply-add runs at full rate, a
                     // 32-bit integer multiply at a quarter of it (this loop was 135 v_mul_lo_u32 in the kernel's ISA)
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(const PreParams p)
     }
 
     // vertical taps + normalise, 4 pixels per thread; input channel order is BGR, output RGB0
-    for (int idx = tid; idx < PRE_TY * (PRE_OUT / 4); idx += 256) {
+    for (int idx = tid; idx < PRE_TY * (PRE_OUT / 4); idx += PRE_NT) {
         const int ty = idx / (PRE_OUT / 4), g = idx - ty * (PRE_OUT / 4);
         const int oy = oy0 + ty;
         if (oy >= PRE_OUT) break;
@@ -332,13 +342,13 @@ int vtd_launch_preprocess(const uint8_t* frames, int n, int H, int W, half_t* ou
                     VTD_HIP_CHECK(hipFuncSetAttribute((const void*)preprocess_fast_kernel<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     attr5 = true;
                 }
-                hipLaunchKernelGGL((preprocess_fast_kernel<5, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(256), lds_fast, stream, p);
+                hipLaunchKernelGGL((preprocess_fast_kernel<5, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(PRE_NT), lds_fast, stream, p);
             } else {
                 if (!attr7) {
                     VTD_HIP_CHECK(hipFuncSetAttribute((const void*)preprocess_fast_kernel<7, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     attr7 = true;
                 }
-                hipLaunchKernelGGL((preprocess_fast_kernel<7, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(256), lds_fast, stream, p);
+                hipLaunchKernelGGL((preprocess_fast_kernel<7, 5>), dim3(PRE_OUT / PRE_TY, n), dim3(PRE_NT), lds_fast, stream, p);
             }
             return -(int)hipGetLastError();
         }
