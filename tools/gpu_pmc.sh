@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the detector's kernels (one pass, 8 SQ slots; no trace domains beside --pmc)
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/pmc_sq
+out=gpurun_out/pmc_sq; rm -rf $out
 mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/p1 -o run -- python3 bench.py --workload detector --cpu-seconds 0 --no-profile --steps 3 --warmup 1 > $out/p1.log 2>&1
@@ -33,3 +33,4 @@ for k, v in res.items():
     print(k, {c: v[c] for c in v if not c.startswith("SQ_")})
 json.dump(res, open("gpurun_out/pmc_sq/summary.json", "w"), indent=1, sort_keys=True)
 PY
+rm -rf gpurun_out/pmc_sq/p1 gpurun_out/pmc_sq/p2   # (the counter CSVs exceed what gpurun merges back; the summary above is what profiles/ keeps)
