@@ -176,11 +176,11 @@ __global__ __launch_bounds__(PRE_NT) void preprocess_fast_kernel(const PreParams
     }
 
     const int quads = p.W >> 2;  // 4 pixels = 12 bytes = 3 dwords (W % 4 == 0 on this path)
-    // raw rows travel HBM -> registers -> LDS; the registers of chunk c+1 are loaded before chunk c is resampled, so the
-    // memory latency (~2 us) hides behind the horizontal taps instead of being paid once per chunk
+    // raw rows travel HBM -> registers -> LDS, two chunks ahead: the registers of chunks c+1 and c+2 are in flight while chunk c is
+    // resampled (one chunk ahead left the waves waiting for memory: a chunk's taps take about 1 us, a load 2-3 us)
     constexpr int MAXIT = (PRE_CHUNK * 512 + PRE_NT - 1) / PRE_NT;  // PRE_CHUNK * (W / 4) / PRE_NT <= MAXIT  <=>  W <= 2048 (checked by the launcher)
-    uint32_t stg[MAXIT][3];
-    auto fetch = [&](int r0) {
+    uint32_t stg0[MAXIT][3], stg1[MAXIT][3];
+    auto fetch = [&](int r0, uint32_t (&stg)[MAXIT][3]) {
         const int nr = min(PRE_CHUNK, nrows - r0);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -192,8 +192,7 @@ __global__ __launch_bounds__(PRE_NT) void preprocess_fast_kernel(const PreParams
             }
         }
     };
-    fetch(0);
-    for (int r0 = 0; r0 < nrows; r0 += PRE_CHUNK) {
+    auto chunk = [&](int r0, uint32_t (&stg)[MAXIT][3]) {   // stage chunk r0 from its registers, refill them with chunk r0 + 2, resample
         const int nr = min(PRE_CHUNK, nrows - r0);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(PRE_NT) void preprocess_fast_kernel(const PreParams
             }
         }
         __syncthreads();
-        if (r0 + PRE_CHUNK < nrows) fetch(r0 + PRE_CHUNK);
+        if (r0 + 2 * PRE_CHUNK < nrows) fetch(r0 + 2 * PRE_CHUNK, stg);
         for (int rr = 0; rr < nr; ++rr) {
             const uint32_t* row = raw + rr * raw_pitch;
 #pragma unroll
@@ -233,6 +232,12 @@ __global__ __launch_bounds__(PRE_NT) void preprocess_fast_kernel(const PreParams
             }
         }
         __syncthreads();
+    };
+    fetch(0, stg0);
+    if (PRE_CHUNK < nrows) fetch(PRE_CHUNK, stg1);
+    for (int r0 = 0; r0 < nrows; r0 += 2 * PRE_CHUNK) {
+        chunk(r0, stg0);
+        if (r0 + PRE_CHUNK < nrows) chunk(r0 + PRE_CHUNK, stg1);
     }
 
     // vertical taps + normalise, 4 pixels per thread; input channel order is BGR, output RGB0
