@@ -61,6 +61,31 @@ def test_error_strings_and_argument_validation_without_device():
     lib.vtd_detector_destroy(h)
 
 
+def test_transformer_handle_options_without_device():
+    """vtd_trocr_set_option / vtd_trocr_get_option (include/vtd.h): the cross-attention form and the slot count are build options of the
+    handle; bad values and unknown names are refused, nothing here touches a GPU."""
+    from vtd_amd.trocr_spec import TINY as spec
+    lib = _native.load()
+    cfg = _native.TrocrConfig(spec.image_size, spec.patch_size, spec.enc_hidden, spec.enc_layers, spec.enc_heads, spec.enc_ffn,
+                              int(spec.enc_qkv_bias), spec.enc_ln_eps, spec.dec_hidden, spec.dec_layers, spec.dec_heads, spec.dec_ffn,
+                              spec.vocab_size, spec.max_positions, spec.dec_ln_eps, spec.decoder_start_token_id, spec.eos_token_id,
+                              spec.pad_token_id, spec.max_length)
+    h = ctypes.c_void_p()
+    assert lib.vtd_trocr_create(ctypes.byref(cfg), 8, ctypes.byref(h)) == 0
+    v = ctypes.c_int(-1)
+    assert lib.vtd_trocr_get_option(h, b"xattn", ctypes.byref(v)) == 0 and v.value == 1      # the default form
+    assert lib.vtd_trocr_get_option(h, b"slots", ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.vtd_trocr_set_option(h, b"xattn", 0) == 0
+    assert lib.vtd_trocr_get_option(h, b"xattn", ctypes.byref(v)) == 0 and v.value == 0
+    assert lib.vtd_trocr_set_option(h, b"xattn", 2) == 0
+    assert lib.vtd_trocr_get_option(h, b"xattn", ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.vtd_trocr_set_option(h, b"xattn", 3) != 0 and lib.vtd_trocr_set_option(h, b"slots", 3) != 0
+    assert lib.vtd_trocr_set_option(h, b"slots", 2) == 0
+    assert lib.vtd_trocr_get_option(h, b"slots", ctypes.byref(v)) == 0 and v.value == 2
+    assert lib.vtd_trocr_set_option(h, b"no such option", 1) != 0 and lib.vtd_trocr_get_option(h, b"no such option", ctypes.byref(v)) != 0
+    lib.vtd_trocr_destroy(h)
+
+
 def test_head_entry_half_halo_schedule_is_hazard_free_and_complete():
     """head_entry_half.hip walks the composed head entry's K in half-steps on two 32-channel half halos that are refilled while
     the other half is multiplied.  The host-built schedule (no GPU needed) must (a) pass its own replay -- no half halo read
