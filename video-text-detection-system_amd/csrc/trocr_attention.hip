@@ -3,10 +3,12 @@
 //
 //   S^T = K Q^T    so a lane owns one query column: the online softmax runs on the accumulator registers (two shfl_xor per reduction)
 //                  and the probabilities feed the second MFMA directly as its K-permuted operand -- no LDS round trip for P;
-//   O^T = V^T P^T  needs V with the KEYS contiguous.  The first version transposed V while staging it (eight 2-byte LDS writes per
-//                  thread and key block, behind two barriers per 32 keys, 64 queries per workgroup): 1.3 ms per layer at 272 crops =
-//                  0.21 PFLOP/s.  Now a small pre-pass (trocr_vt_kernel) writes V^T per (crop, head) once -- [64][Tpad] fp16, zero padded --
-//                  and the attention kernel stages K [64 keys][64] and V^T [64][64 keys] tiles with plain 16-byte accesses;
+//   O^T = V^T P^T  needs V with the KEYS contiguous in a lane's operand.  The first version transposed V while staging it (eight 2-byte LDS
+//                  writes per thread and key block: 1.3 ms per layer at 272 crops); the second had a pre-pass write V^T per (crop, head) to
+//                  HBM once per layer (105 us per layer, 1 MB per crop) and read V^T tiles.  Now V is staged exactly as K is -- [64 keys][64]
+//                  rows straight out of the qkv tensor -- and the operand is formed by gfx950's transposed LDS read: ds_read_b64_tr_b16 hands a
+//                  lane four KEYS of one channel, two of them make the 8-deep fragment in the key order the probabilities come out in.  No
+//                  pre-pass, no V^T buffer, the same products in the same order (bit-identical results).
 //   tile           128 queries per workgroup (4 waves x 2 query fragments) against key blocks of 64: the K / V^T tile traffic and the
 //                  barriers per query are a quarter of the first version's; the next block's tiles are fetched into registers while the
 //                  current block multiplies (one barrier pair per 64 keys).
@@ -21,51 +23,17 @@ constexpr int AT_PADK = 80;    // halfs per LDS row of the K tile.  160 bytes: i
                                // 72 (144 bytes), conflict-free only for groups of consecutive lanes: SQ_LDS_BANK_CONFLICT was 40 % of the kernel's
                                // LDS cycles (tools/gpu_pmc_trocr.sh).  The staging stores stay conflict-free at this pitch because odd rows
                                // write the second 16 bytes of their 32-byte piece first (`sw` below).
-constexpr int AT_PADV = 72;    // ... of the V^T tile: it is read with ds_read_b64 (two groups of 32 lanes, 64 banks): 144 bytes spread the 16
-                               // rows of a fragment over 16 different 16-byte slots (160 would fold rows r and r + 8 onto one)
+                               // The V tile has the same pitch: its transposed reads (32-lane halves: 8 keys x 32 bytes) then fall on eight
+                               // different 32-byte bank groups (r x 160 mod 256 = 0, 160, 64, 224, 128, 32, 192, 96).
+typedef __fp16 at_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// V^T[b][head][d][t] = qkv[b][t][2 C + head * 64 + d], t < T (zeros up to Tpad).  Workgroup = 64 tokens of one (b, head).
-__global__ __launch_bounds__(256) void trocr_vt_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ vt, int T, int Tpad, int C) {
-    __shared__ half_t tile[64 * 66];
-    const int b = blockIdx.z, head = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
-    const int64_t ld = 3 * (int64_t)C;
-    {
-        const int row = tid >> 2, seg = (tid & 3) * 16;   // token row, 16 halfs of its 64
-        const int t = t0 + row;
-        half8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = a;
-        if (t < T) {
-            const half_t* src = qkv + ((int64_t)b * T + t) * ld + 2 * C + head * 64 + seg;
-            a = *(const half8*)src;
-            c = *(const half8*)(src + 8);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            tile[(seg + e) * 66 + row] = a[e];
-            tile[(seg + 8 + e) * 66 + row] = c[e];
-        }
-    }
-    __syncthreads();
-    {
-        const int d = tid >> 2, seg = (tid & 3) * 16;     // output row d, 16 tokens of the 64
-        half_t* dst = vt + (((int64_t)b * gridDim.y + head) * 64 + d) * Tpad + t0 + seg;
-        half8 a, c;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a[e] = tile[d * 66 + seg + e];
-            c[e] = tile[d * 66 + seg + 8 + e];
-        }
-        if (t0 + seg < Tpad) *(half8*)dst = a;
-        if (t0 + seg + 8 < Tpad) *(half8*)(dst + 8) = c;
-    }
-}
-
-__global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ vt, half_t* __restrict__ out,
-                                                              int T, int Tpad, int C, float scale, int heads, int units, int qtiles) {
+__global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int C, float scale,
+                                                              int heads, int units, int qtiles) {
     __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PADK];   // K tile, key-major
-    __shared__ __attribute__((aligned(16))) half_t vs[2][64 * AT_PADV];      // V^T tile, d-major
-    // Workgroup -> (crop, head, query tile).  The query tiles of one (crop, head) read the same K and V^T rows (148 KB): they must run on
+    __shared__ __attribute__((aligned(16))) half_t vs[2][AT_KB * AT_PADK];   // V tile, key-major as well (read transposed)
+    // Workgroup -> (crop, head, query tile).  The query tiles of one (crop, head) read the same K and V rows (148 KB): they must run on
     // ONE XCD to find them in its L2.  Consecutive workgroup ids go to different XCDs, so XCD x = id % 8 takes the units x, x + 8, ...
-    // and walks each unit's `qtiles` tiles back to back (PMC before: 3.0 GB read per launch at 287 crops, every tile fetching K / V^T
+    // and walks each unit's `qtiles` tiles back to back (PMC before: 3.0 GB read per launch at 287 crops, every tile fetching K / V
     // from HBM; algorithmic 1.0 GB).
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int unit = (idx / qtiles) * 8 + xcd, qt = idx - (idx / qtiles) * qtiles;
@@ -74,7 +42,6 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int64_t ld = 3 * (int64_t)C;
     const half_t* base = qkv + (int64_t)b * T * ld + head * 64;
-    const half_t* vbase = vt + ((int64_t)b * heads + head) * 64 * Tpad;
     // Q fragments (second MFMA operand: column = query fr, K chunk fq), pre-scaled; wave w owns queries q0 + 32 w + 16 g + fr
     half8 qf[2][2];
 #pragma unroll
@@ -104,15 +71,15 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
         const half_t* ksrc = base + (int64_t)key * ld + C + scol;
         kreg[0] = *(const half8*)(ksrc + sw);
         kreg[1] = *(const half8*)(ksrc + (8 - sw));
-        const half_t* vsrc = vbase + (int64_t)srow * Tpad + k0 + scol;   // d = srow, keys k0 + scol .. (zero padded to Tpad)
-        vreg[0] = *(const half8*)vsrc;
-        vreg[1] = *(const half8*)(vsrc + 8);
+        const half_t* vsrc = ksrc + C;   // the same key's value row (rows past the end: their probabilities are exactly 0, the row is finite)
+        vreg[0] = *(const half8*)(vsrc + sw);
+        vreg[1] = *(const half8*)(vsrc + (8 - sw));
     };
     auto stage = [&](int buf, const half8* kreg, const half8* vreg) {
         *(half8*)(&ks[buf][srow * AT_PADK + scol + sw]) = kreg[0];
         *(half8*)(&ks[buf][srow * AT_PADK + scol + (8 - sw)]) = kreg[1];
-        *(half8*)(&vs[buf][srow * AT_PADV + scol]) = vreg[0];
-        *(half8*)(&vs[buf][srow * AT_PADV + scol + 8]) = vreg[1];
+        *(half8*)(&vs[buf][srow * AT_PADK + scol + sw]) = vreg[0];
+        *(half8*)(&vs[buf][srow * AT_PADK + scol + (8 - sw)]) = vreg[1];
     };
     half8 kreg[2], vreg[2];
     fetch(0, kreg, vreg);
@@ -181,8 +148,11 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const half4 va = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PADV + h * 32 + fq * 4]);
-                const half4 vb = *(const half4*)(&vs[buf][(i * 16 + fr) * AT_PADV + h * 32 + 16 + fq * 4]);
+                // lane 4 q + r of a 16-lane group hands in the address of key row 32 h + 4 fq + q (+ 16), channels 16 i + 4 r ..; lane fr gets
+                // channel 16 i + fr of those four keys
+                const half_t* vrow = &vs[buf][(h * 32 + fq * 4 + (fr >> 2)) * AT_PADK + i * 16 + (fr & 3) * 4];
+                const half4 va = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((VTD_AS3 at_fp16x4*)vrow));
+                const half4 vb = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((VTD_AS3 at_fp16x4*)(vrow + 16 * AT_PADK)));
                 const half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
                 for (int g = 0; g < 2; ++g) acc_o[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[g][h], acc_o[g][i], 0, 0, 0);
@@ -214,15 +184,10 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
 
 }  // namespace
 
-// keys padded to a multiple of the key block (+ one block so that the tile fetch of the last block stays inside the row)
-int vtd_trocr_attention_tpad(int T) { return (T + AT_KB - 1) / AT_KB * AT_KB; }
-
-int vtd_launch_trocr_attention(const half_t* qkv, half_t* vt, half_t* out, int n, int T, int C, int heads, hipStream_t s) {
-    if (heads * 64 != C || n <= 0 || T <= 0 || !vt) return -2404;
-    const int Tpad = vtd_trocr_attention_tpad(T);
-    hipLaunchKernelGGL(trocr_vt_kernel, dim3(Tpad / 64, heads, n), dim3(256), 0, s, qkv, vt, T, Tpad, C);
+int vtd_launch_trocr_attention(const half_t* qkv, half_t* out, int n, int T, int C, int heads, hipStream_t s) {
+    if (heads * 64 != C || n <= 0 || T <= 0) return -2404;
     const int qtiles = (T + 127) / 128, units = heads * n;
     const int64_t grid = (int64_t)((units + 7) / 8) * 8 * qtiles;
-    hipLaunchKernelGGL(trocr_attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, qkv, vt, out, T, Tpad, C, 0.125f, heads, units, qtiles);
+    hipLaunchKernelGGL(trocr_attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, T, C, 0.125f, heads, units, qtiles);
     return -(int)hipGetLastError();
 }
