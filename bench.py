@@ -198,6 +198,9 @@ def main():
         # whole video is done, so the reference's caller does not see the difference.
         os.environ.setdefault("VTD_TROCR_PASS_TICKETS", "12" if B <= 32 else "4")
         os.environ.setdefault("VTD_TROCR_MAX_CROPS", "3456" if B <= 32 else "2560")
+        # a full pass runs on the engine's worker thread while this thread keeps feeding the detector: the detector's launches of the next
+        # pass's batches fall into the decode's launch-bound tail (+1 % here, +4.5 % on configs[4] with its 5.5-ms ResNet-50 detector passes)
+        os.environ.setdefault("VTD_TROCR_ASYNC", "1")
         os.environ.setdefault("VTD_TROCR_SEEDED", "0")   # explicit opt-in: the architecture on synthetic weights (nothing is fetchable)
     pipe = VideoTextPipeline(use_transformer_ocr=args.recognizer == "trocr", backbone=args.backbone, batch_size=B)
     pipe.detector.max_detections = MAX_DET = 64

@@ -423,3 +423,39 @@ def test_cross_attention_on_the_encoder_states_equals_the_key_value_form(tiny, b
                 assert got == [r["ids"] for r in man]
         finally:
             other.close()
+
+
+def test_passes_on_the_worker_thread_equal_the_synchronous_calls(base, monkeypatch):
+    """VTD_TROCR_ASYNC=1: a full pass (two tickets here) goes to the engine's worker thread, which stages, encodes and decodes it while the
+    submitting thread carries on; finish() of such a ticket waits for the worker, finish() of a ticket still in the queue flushes it in
+    the calling thread.  Five tickets -> two passes on the worker + one leftover: every ticket's ids equal generate_crops on its own boxes;
+    discard_queue drops what the worker has not started."""
+    from vtd_amd.engine import DeviceFrames, TrOCREngine
+    eng, sd = base
+    monkeypatch.setenv("VTD_TROCR_ASYNC", "1")
+    monkeypatch.setenv("VTD_TROCR_PASS_TICKETS", "2")
+    a = TrOCREngine(BASE_PRINTED, sd, max_crops=16)
+    try:
+        assert a.async_passes and a.pipeline_lag == 3
+        batches = []
+        for gi in range(5):
+            frames, boxes = _crops_in_frames([synth.glyph_crop(1100 + 7 * gi + i) for i in range(3 + gi % 2)])
+            batches.append((DeviceFrames(frames), boxes))
+        want = [eng.generate_crops(fr, bx).numpy() for fr, bx in batches]
+        tickets = [a.submit_crops(fr, bx) for fr, bx in batches]
+        assert all("ready" in t for t in tickets[:4]) and "ready" not in tickets[4]
+        for i in (4, 0, 3, 1, 2):      # any order
+            assert np.array_equal(a.finish(tickets[i]).numpy(), want[i]), i
+        # an abandoned video: queued passes are dropped, their tickets report the failure instead of hanging
+        more = [a.submit_crops(fr, bx) for fr, bx in batches[:4]]
+        a.discard_queue()
+        for t in more:
+            try:
+                a.finish(t)
+            except Exception:
+                pass
+        t = a.submit_crops(*batches[0])
+        t2 = a.submit_crops(*batches[1])
+        assert np.array_equal(a.finish(t).numpy(), want[0]) and np.array_equal(a.finish(t2).numpy(), want[1])
+    finally:
+        a.close()

@@ -536,10 +536,15 @@ class TrOCREngine(_Tunable):
         self.xattn = bool(form.value)   # the form that runs (a geometry the kernel does not cover keeps the key / value form)
         self._next_slot = 0
         self._queue = []          # tickets whose crops are not staged yet (submit_crops / finish)
+        self._qlock = threading.Lock()
         self._passes = []         # encoded passes that wait for their decode, oldest first
         self._setup_overlap()
 
     def close(self):
+        if getattr(self, "_worker", None) is not None and self._worker.is_alive() and not sys.is_finalizing():
+            self._generation = getattr(self, "_generation", 0) + 1
+            self._jobs.put(None)
+            self._worker.join(timeout=60)
         if getattr(self, "handle", None):
             if not sys.is_finalizing():   # work may still be queued on the shared encoder / decode streams
                 try:
@@ -655,7 +660,15 @@ class TrOCREngine(_Tunable):
             except Exception as e:   # no CU masks on this stack: the back-to-back order
                 logger.warning(f"TrOCREngine: CU-masked streams unavailable ({e}); encoder pass and decode run back to back")
                 self._enc_stream = self._dec_stream = None
-        self.pipeline_lag = 2 * self.pass_tickets - 1 if self.overlap else max(1, self.pass_tickets - 1)
+        # Asynchronous passes (VTD_TROCR_ASYNC=1): a full pass (pass_tickets tickets) goes to a worker thread, which stages, encodes and
+        # decodes it while the submitting thread keeps feeding the detector -- a pass blocks its host thread for its whole (host-paced)
+        # decode, during which the caller's thread otherwise submits nothing: the detector's launches of the next pass's batches then fall
+        # into the decode's launch-bound tail instead of running while the recogniser's streams sit idle.  The caller keeps two passes of
+        # tickets in flight (pipeline_lag = 2 pass_tickets - 1).
+        self.async_passes = os.environ.get("VTD_TROCR_ASYNC", "0") == "1" and not self.overlap
+        self._jobs = self._worker = None
+        self._generation = 0
+        self.pipeline_lag = 2 * self.pass_tickets - 1 if (self.overlap or self.async_passes) else max(1, self.pass_tickets - 1)
 
     def submit_crops(self, frames, boxes):
         """Queue the crops `boxes` ([(frame, x1, y1, x2, y2), ...]) of a resident frame batch; returns a ticket for ``finish``.  Nothing
@@ -663,30 +676,73 @@ class TrOCREngine(_Tunable):
         at once)."""
         b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
         ticket = {"boxes": b, "frames": frames, "stream": torch.cuda.current_stream(), "parts": None}
+        if self.async_passes and os.environ.get("VTD_TROCR_MERGE", "1") != "0":
+            # (the engine lock is the worker's for the whole of a pass: the queue has a lock of its own, so submitting never waits for one)
+            job = None
+            with self._qlock:
+                self._queue.append(ticket)
+                if len(self._queue) >= self.pass_tickets:
+                    group, self._queue = self._queue[:self.pass_tickets], self._queue[self.pass_tickets:]
+                    for t in group:
+                        t["ready"] = threading.Event()
+                    job = (self._generation, group, torch.cuda.current_device())
+            if job is not None:
+                self._start_worker()
+                self._jobs.put(job)
+            return ticket
         with self.lock:
-            if getattr(self, "_queue", None) is None:
-                self._queue = []
             room = self.max_crops * (self.slots if self.overlap else 1)
             if sum(len(t["boxes"]) for t in self._queue) + len(b) > room:
                 self._flush()
-            self._queue.append(ticket)
+            with self._qlock:
+                self._queue.append(ticket)
             if os.environ.get("VTD_TROCR_MERGE", "1") == "0":
                 self._flush()
         return ticket
+
+    def _start_worker(self):
+        if self._worker is None or not self._worker.is_alive():
+            import queue as _queue
+            self._jobs = _queue.Queue()
+            self._worker = threading.Thread(target=self._worker_loop, name="vtd-trocr-pass", daemon=True)
+            self._worker.start()
+
+    def _worker_loop(self):
+        jobs = self._jobs
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            generation, group, device = job
+            try:
+                torch.cuda.set_device(device)
+                with self.lock:
+                    if generation == self._generation and getattr(self, "handle", None):   # (discard_queue / close bump the generation)
+                        self._run_groups([group], group)
+            except Exception as e:   # finish() reports it per ticket (parts stay None), as for a synchronous pass that raised
+                logger.error(f"TrOCREngine: recogniser pass failed: {e}")
+            finally:
+                for t in group:
+                    t["ready"].set()
 
     def _flush(self):
         """Everything queued is cut into passes and their encoder passes are enqueued (lock held).  Back-to-back mode decodes every pass
         at once; overlap mode leaves the decodes to ``finish`` (and runs the oldest ones only when the slots run out).  Tickets larger
         than the workspace are cut into passes of max_crops rows; every ticket ends up with a list of (pass, spans)."""
-        queue, self._queue = getattr(self, "_queue", None) or [], []
+        with self._qlock:
+            queue, self._queue = self._queue, []
         if not queue:
             return
-        if getattr(self, "_passes", None) is None:
-            self._passes = []
         merge = os.environ.get("VTD_TROCR_MERGE", "1") != "0"
         groups, k = [], (self.pass_tickets if merge else 1)
         for i in range(0, len(queue), k):
             groups.append(queue[i:i + k])
+        self._run_groups(groups, queue)
+
+    def _run_groups(self, groups, queue):
+        """Stage + encode (+ decode, back to back) the ticket groups, one or more passes each (lock held)."""
+        if getattr(self, "_passes", None) is None:
+            self._passes = []
         parts = {id(t): [] for t in queue}
         for group in groups:
             rows = [(t, i) for t in group for i in range(len(t["boxes"]))]
@@ -767,13 +823,17 @@ class TrOCREngine(_Tunable):
         """ids [n, max_length] int32 (cpu) of a ticket, rows in the order of its boxes.  Flushes the queue when the ticket is still in
         it (every ticket queued by then gets its encoder pass enqueued: the passes behind this ticket's run beside its decode).
         Host-blocking: returns when this ticket's decode has finished."""
-        with self.lock:
-            if ticket["parts"] is None:
-                self._flush()
-            if ticket["parts"] is not None:
-                for pas, _ in ticket["parts"]:
-                    while not pas["decoded"]:          # passes decode in the order they were encoded
-                        self._decode_pass(self._passes[0])
+        ready = ticket.get("ready")
+        if ready is not None:
+            ready.wait()               # its pass runs (or ran) on the worker thread: encoded and decoded when the event is set
+        else:
+            with self.lock:
+                if ticket["parts"] is None:
+                    self._flush()
+                if ticket["parts"] is not None:
+                    for pas, _ in ticket["parts"]:
+                        while not pas["decoded"]:          # passes decode in the order they were encoded
+                            self._decode_pass(self._passes[0])
         if ticket["parts"] is None:    # its pass raised half way (the exception went to whoever triggered the flush)
             raise _native.NativeError("the recogniser pass this ticket was queued for failed")
         n = len(ticket["boxes"])
@@ -799,10 +859,12 @@ class TrOCREngine(_Tunable):
         """Drop every ticket that has not been finished (an abandoned video): queued tickets release their frame batches, encoded
         passes are forgotten (their slots are reused in order; the handle's events keep the GPU side consistent)."""
         with self.lock:
-            for t in getattr(self, "_queue", None) or []:
-                t["frames"] = None
-                t["parts"] = None
-            self._queue = []
+            self._generation = getattr(self, "_generation", 0) + 1   # passes still waiting for the worker are dropped when it gets to them
+            with self._qlock:
+                for t in self._queue:
+                    t["frames"] = None
+                    t["parts"] = None
+                self._queue = []
             for pas in getattr(self, "_passes", None) or []:
                 pas["decoded"] = pas["failed"] = True
             self._passes = []
