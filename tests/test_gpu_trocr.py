@@ -459,3 +459,25 @@ def test_passes_on_the_worker_thread_equal_the_synchronous_calls(base, monkeypat
         assert np.array_equal(a.finish(t).numpy(), want[0]) and np.array_equal(a.finish(t2).numpy(), want[1])
     finally:
         a.close()
+
+
+def test_panel_major_gemm_inputs_change_no_bit(base, monkeypatch):
+    """The encoder pass's dense layers read their fp16 inputs and weights K-panel-major ([K / 32][rows][32]: an LDS-DMA piece of the dense
+    GEMM is then 1 KB of contiguous memory; the LayerNorm, the attention and the GELU GEMM write that order when every consumer of the pass
+    is a dense GEMM).  Same values, same products, same order: encoder states and logits equal the row-major build's (VTD_DENSE_PANEL=0) bit
+    for bit, at a pass size that takes the dense path."""
+    from vtd_amd.engine import TrOCREngine
+    eng, sd = base
+    monkeypatch.setenv("VTD_DENSE_GEMM", "1")          # the dense path wherever the shape allows (16 crops x 577 tokens = 37 row tiles)
+    x = torch.stack([otrocr.preprocess(synth.glyph_crop(1200 + i), BASE_PRINTED) for i in range(16)])
+    outs = []
+    for panel in ("1", "0"):
+        monkeypatch.setenv("VTD_DENSE_PANEL", panel)
+        e = TrOCREngine(BASE_PRINTED, sd, max_crops=16)
+        try:
+            ids, lg = e.generate_pixels(x, want_logits=True, max_length=6)
+            outs.append((e.read_tap("encoder", 16).copy(), ids.numpy().copy(), lg.numpy().copy()))
+        finally:
+            e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert float(np.abs(outs[0][0]).max()) > 0.1

@@ -36,6 +36,13 @@ struct DenseGemmParams {
     int M, N, K, lda, ldc, w_rows, tiles_n, flags;   // flags: EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU
     int tiles_m, gn, blocks_n;                       // tile order: super-blocks of DGM_GM x gn tiles per XCD (gn = 0: row-major runs)
     int nvb;                                         // virtual block ids to walk (tiles incl. the padding of the last super-block row)
+    // Operand addressing, in elements: element (row, k) of A lives at row * a_rs + (k / 32) * a_ks + k % 32.  Row-major: a_rs = lda, a_ks = 32.
+    // K-PANEL-MAJOR ([K / 32][rows][32]: a_rs = 32, a_ks = 32 x the producer's row count): the 16 rows x 64 bytes of an LDS-DMA piece are then
+    // 1 KB of contiguous memory -- eight whole cache lines -- where the row-major layout makes them sixteen half lines (the BK = 32 stage is
+    // 64 bytes of a row); measured on the encoder's shapes with a timing-only variant first: +7...10 % (tools/dense_gemm_bench.py).
+    int a_rs, b_rs;
+    int64_t a_ks, b_ks;
+    int64_t out_prows;   // fp16 output in the same panel layout for the next GEMM ([N / 32][out_prows][32]); 0: row-major [M][ldc]
 };
 constexpr int DGM_GM = 8;
 
@@ -117,13 +124,13 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             const int chunk = (lane & 3) ^ dgm_key(row);
             int m = t.m0 + row;
             m = m < p.M ? m : p.M - 1;                       // rows past the end re-read the last row (never written)
-            t.a[i] = m * p.lda + chunk * 8;
+            t.a[i] = m * p.a_rs + chunk * 8;
             // B row `row` of the tile feeds MFMA row (row & 15) of fragment (row >> 4) & 3 of wave column row >> 6; it is fed with the
             // weights of the channel that makes a lane's accumulators 8 consecutive channels (see the epilogue)
             const int x = row & 63, blk = x >> 4, rr = x & 15;
             int n = t.n0 + (row - x) + 32 * (blk >> 1) + 8 * (rr >> 2) + 4 * (blk & 1) + (rr & 3);
             n = n < p.w_rows ? n : p.w_rows - 1;
-            t.b[i] = n * p.K + chunk * 8;
+            t.b[i] = n * p.b_rs + chunk * 8;
         }
     };
     int g = 0;                    // global stage counter of this workgroup: stage s of its t-th tile is g = t S + s, ring slot g & 3
@@ -131,6 +138,9 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
         if constexpr ((VAR & 32) != 0) { if (g >= 1) return; }   // TIMING ONLY (wrong results): no operand traffic after the prologue
         char* base = dgm_smem + slot * DGM_STAGE;
         const int k = stage * DGM_BK;
+        const half_t* const Ak = p.A + (int64_t)stage * p.a_ks;   // (wave-uniform: a scalar base; the lane adds its 32-bit offset)
+        const half_t* const Wk = p.W + (int64_t)stage * p.b_ks;
+        (void)k;
         if constexpr ((VAR & 4) != 0) {
             // TIMING EXPERIMENT ONLY (wrong results): every piece reads 1 KB of CONTIGUOUS memory (eight full 128-byte lines) instead of
             // sixteen 64-byte half lines -- same instruction count, same bytes: does the half-line gather cost anything?
@@ -150,12 +160,12 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
         if (part & 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.A + (t.a[i] + k)), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(Ak + (unsigned)t.a[i]), (VTD_AS3 void*)(base + (w + 8 * i) * 1024), 16, 0, 0);
         }
         if (part & 2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(p.W + (t.b[i] + k)), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const VTD_AS1 void*)(Wk + (unsigned)t.b[i]), (VTD_AS3 void*)(base + DGM_BM * 64 + (w + 8 * i) * 1024), 16, 0, 0);
         }
     };
     // Where a stage's four LDS-DMA instructions are issued: PART_R of them in the R interval (behind the fragment reads, while the other
@@ -185,6 +195,9 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
             const int n = n0 + wn * 64 + jp * 32 + fq * 8;
             if (n >= p.N) continue;
             const floatx4 b0 = *(const floatx4*)(p.bias + n), b1 = *(const floatx4*)(p.bias + n + 4);
+            // output element (m, n) at m * o_rs + coff: row-major o_rs = ldc, coff = n; panel-major o_rs = 32, coff = (n / 32) * 32 out_prows + n % 32
+            const int64_t o_rs = p.out_prows ? 32 : p.ldc;
+            const int64_t coff = p.out_prows ? ((int64_t)(n >> 5) * p.out_prows << 5) + (n & 31) : n;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = m0 + wm * 128 + i * 16 + fr;
@@ -198,9 +211,9 @@ __global__ __launch_bounds__(512) void dense_gemm_kernel(const DenseGemmParams p
                     half8 h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = (half_t)v0[e]; h[4 + e] = (half_t)v1[e]; }
-                    *(half8*)((half_t*)p.out + (int64_t)m * p.ldc + n) = h;
+                    *(half8*)((half_t*)p.out + (int64_t)m * o_rs + coff) = h;
                 } else {
-                    float* o = (float*)p.out + (int64_t)m * p.ldc + n;
+                    float* o = (float*)p.out + (int64_t)m * o_rs + coff;
                     *(floatx4*)o = v0;
                     *(floatx4*)(o + 4) = v1;
                 }
@@ -326,27 +339,35 @@ bool vtd_dense_gemm_supported(int64_t M, int N, int K, int lda, int ldc, int fla
     return tiles >= 512;
 }
 
-int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows, const float* bias, void* out, int ldc, int64_t M, int N, int K,
-                          int flags, hipStream_t stream) {
+// a_prows / out_prows: row count of the K-panel-major A operand / fp16 output ([K / 32][prows][32]), 0 for row-major; w_panel: the weights are
+// [K / 32][w_rows][32].
+int vtd_launch_dense_gemm_ex(const half_t* A, int lda, int64_t a_prows, const half_t* W, int w_rows, int w_panel, const float* bias, void* out, int ldc,
+                             int64_t out_prows, int64_t M, int N, int K, int flags, hipStream_t stream) {
     if (M < 256 || N < 256 || (N & 7) || (K & 31) || K < 128 || (lda & 7) || (ldc & 7) || M > 0x7fffffff ||
         !(flags & (EPI_OUT_F16 | EPI_OUT_F32)) || (flags & ~(EPI_OUT_F16 | EPI_OUT_F32 | EPI_GELU)) || (int64_t)w_rows * K >= 0x7fffffff)
         return -2601;
-    if (M * (int64_t)lda >= 0x7fffffff) {
-        // the kernel addresses A with 32-bit element offsets: a taller operand (a recogniser pass of > ~1200 crops at the 3072-wide fc2
-        // input) runs as row blocks, each a launch of its own on the same stream -- every output row is computed exactly as before
+    if ((a_prows && (a_prows < M || a_prows * 32 >= 0x7fffffff)) || (out_prows && (out_prows < M || !(flags & EPI_OUT_F16) || (N & 31)))) return -2601;
+    if (!a_prows && M * (int64_t)lda >= 0x7fffffff) {
+        // the kernel addresses a row-major A with 32-bit element offsets: a taller operand (a recogniser pass of > ~1200 crops at the
+        // 3072-wide fc2 input) runs as row blocks, each a launch of its own on the same stream -- every output row is computed exactly as
+        // before.  (A panel-major A has 32 elements per row and panel: no such bound.)
         const int64_t rows = ((int64_t)0x7ffffffe / lda) / DGM_BM * DGM_BM;
         if (rows < DGM_BM) return -2601;
         const size_t esz = (flags & EPI_OUT_F16) ? sizeof(half_t) : sizeof(float);
+        auto out_at = [&](int64_t m0) { return out_prows ? (void*)((half_t*)out + m0 * 32) : (void*)((char*)out + (size_t)m0 * ldc * esz); };
         for (int64_t m0 = 0; m0 < M; m0 += rows) {
             const int64_t mb = std::min(rows, M - m0);
             int rc;
-            if (mb >= 256) rc = vtd_launch_dense_gemm(A + m0 * lda, lda, W, w_rows, bias, (char*)out + (size_t)m0 * ldc * esz, ldc, mb, N, K, flags, stream);
-            else rc = vtd_launch_dense_gemm(A + (M - 256) * lda, lda, W, w_rows, bias, (char*)out + (size_t)(M - 256) * ldc * esz, ldc, 256, N, K, flags, stream);  // a short tail: the last 256 rows again (same values)
+            if (mb >= 256) rc = vtd_launch_dense_gemm_ex(A + m0 * lda, lda, 0, W, w_rows, w_panel, bias, out_at(m0), ldc, out_prows, mb, N, K, flags, stream);
+            else rc = vtd_launch_dense_gemm_ex(A + (M - 256) * lda, lda, 0, W, w_rows, w_panel, bias, out_at(M - 256), ldc, out_prows, 256, N, K, flags, stream);  // a short tail: the last 256 rows again (same values)
             if (rc) return rc;
         }
         return 0;
     }
-    DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags, 0, 0, 0, 0};
+    DenseGemmParams p{A, W, bias, out, (int)M, N, K, lda, ldc, w_rows, (N + DGM_BN - 1) / DGM_BN, flags, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    p.a_rs = a_prows ? 32 : lda; p.a_ks = a_prows ? a_prows * 32 : 32;
+    p.b_rs = w_panel ? 32 : K;   p.b_ks = w_panel ? (int64_t)w_rows * 32 : 32;
+    p.out_prows = out_prows;
     p.tiles_m = (int)((M + DGM_BM - 1) / DGM_BM);
     // measurement switches are read ONCE per process (never per launch); 0: row-major runs per XCD (A/B measurements)
     static const int order = [] { const char* e = std::getenv("VTD_DGM_ORDER"); return e ? std::atoi(e) : 1; }();
@@ -434,4 +455,9 @@ int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows,
     else hipLaunchKernelGGL((dense_gemm_kernel<false, 16>), gd, bd, DGM_LDS, stream, p);
 #endif
     return -(int)hipGetLastError();
+}
+
+int vtd_launch_dense_gemm(const half_t* A, int lda, const half_t* W, int w_rows, const float* bias, void* out, int ldc, int64_t M, int N, int K,
+                          int flags, hipStream_t stream) {
+    return vtd_launch_dense_gemm_ex(A, lda, 0, W, w_rows, 0, bias, out, ldc, 0, M, N, K, flags, stream);
 }

@@ -107,7 +107,7 @@ __global__ void trocr_tokens_kernel(const float* __restrict__ patch, const float
 template <int MAXV>
 __global__ __launch_bounds__(256) void trocr_ln_kernel(float* __restrict__ x, const float* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, half_t* __restrict__ out16, float* __restrict__ out32,
-                                                       int rows, int C, float eps, int mode) {
+                                                       int rows, int C, float eps, int mode, int64_t prows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float v[MAXV];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void trocr_ln_kernel(float* __restrict__ x, co
             const float n = (v[i] - mean) * rstd * gamma[c] + beta[c];
             if (mode == 1) x[(int64_t)row * C + c] = v[i];
             if (mode == 2) x[(int64_t)row * C + c] = n;
-            if (out16) out16[(int64_t)row * C + c] = (half_t)n;
+            if (out16) out16[prows ? (((int64_t)(c >> 5) * prows + row) << 5) + (c & 31) : (int64_t)row * C + c] = (half_t)n;
             if (out32) out32[(int64_t)row * C + c] = n;
         }
     }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void trocr_ln_kernel(float* __restrict__ x, co
 template <int MAXV4>
 __global__ __launch_bounds__(256) void trocr_ln4_kernel(float* __restrict__ x, const float* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, half_t* __restrict__ out16, float* __restrict__ out32,
-                                                        int rows, int C, float eps, int mode) {
+                                                        int rows, int C, float eps, int mode, int64_t prows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     floatx4 v[MAXV4];
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void trocr_ln4_kernel(float* __restrict__ x, c
             const floatx4 n = (v[i] - mean) * rstd * g + b;
             if (mode == 1) *(floatx4*)(x + (int64_t)row * C + c) = v[i];
             if (mode == 2) *(floatx4*)(x + (int64_t)row * C + c) = n;
-            if (out16) *(half4*)(out16 + (int64_t)row * C + c) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
+            // (prows: the fp16 GEMM input in K-panel-major order, [C / 32][prows][32] -- dense_gemm.hip reads 1 KB contiguous per LDS-DMA piece)
+            if (out16) *(half4*)(out16 + (prows ? (((int64_t)(c >> 5) * prows + row) << 5) + (c & 31) : (int64_t)row * C + c)) = half4{(half_t)n[0], (half_t)n[1], (half_t)n[2], (half_t)n[3]};
             if (out32) *(floatx4*)(out32 + (int64_t)row * C + c) = n;
         }
     }
@@ -225,18 +226,18 @@ int vtd_launch_trocr_tokens(const float* patch, int ld_patch, const float* cls, 
 }
 
 int vtd_launch_trocr_ln(float* x, const float* y, int ldy, const float* gamma, const float* beta, half_t* out16, float* out32, int rows, int C,
-                        float eps, int mode, hipStream_t s) {
+                        float eps, int mode, int64_t out16_prows, hipStream_t s) {
     if (rows <= 0 || (C & 63) || C > 2048) return -2403;
     const dim3 grid((rows + 3) / 4), block(256);
     const bool al = !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !(ldy & 3) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15) &&
                     !((uintptr_t)out16 & 7) && !((uintptr_t)out32 & 15);
     if (!(C & 255) && al) {
-        if (C <= 1024) hipLaunchKernelGGL(trocr_ln4_kernel<4>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
-        else hipLaunchKernelGGL(trocr_ln4_kernel<8>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
+        if (C <= 1024) hipLaunchKernelGGL(trocr_ln4_kernel<4>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
+        else hipLaunchKernelGGL(trocr_ln4_kernel<8>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
         return -(int)hipGetLastError();
     }
-    if (C <= 1024) hipLaunchKernelGGL(trocr_ln_kernel<16>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
-    else hipLaunchKernelGGL(trocr_ln_kernel<32>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode);
+    if (C <= 1024) hipLaunchKernelGGL(trocr_ln_kernel<16>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
+    else hipLaunchKernelGGL(trocr_ln_kernel<32>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
     return -(int)hipGetLastError();
 }
 

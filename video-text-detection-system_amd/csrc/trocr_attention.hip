@@ -28,7 +28,7 @@ constexpr int AT_PADK = 80;    // halfs per LDS row of the K tile.  160 bytes: i
 typedef __fp16 at_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int C, float scale,
-                                                              int heads, int units, int qtiles) {
+                                                              int heads, int units, int qtiles, int64_t prows) {
     __shared__ __attribute__((aligned(16))) half_t ks[2][AT_KB * AT_PADK];   // K tile, key-major
     __shared__ __attribute__((aligned(16))) half_t vs[2][AT_KB * AT_PADK];   // V tile, key-major as well (read transposed)
     // Workgroup -> (crop, head, query tile).  The query tiles of one (crop, head) read the same K and V rows (148 KB): they must run on
@@ -170,13 +170,14 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
         const int q = q0 + w * 32 + g * 16 + fr;
         if (q < T) {
             const float inv = 1.0f / l;
-            half_t* o = out + ((int64_t)b * T + q) * C + head * 64;
+            const int64_t row = (int64_t)b * T + q;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 half4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc_o[g][i][e] * inv);
-                *(half4*)(o + i * 16 + fq * 4) = hv;
+                const int ch = head * 64 + i * 16 + fq * 4;   // (prows: K-panel-major for the output projection's GEMM, [C / 32][prows][32])
+                *(half4*)(out + (prows ? (((int64_t)(ch >> 5) * prows + row) << 5) + (ch & 31) : row * C + ch)) = hv;
             }
         }
     }
@@ -184,10 +185,10 @@ __global__ __launch_bounds__(256) void trocr_attention_kernel(const half_t* __re
 
 }  // namespace
 
-int vtd_launch_trocr_attention(const half_t* qkv, half_t* out, int n, int T, int C, int heads, hipStream_t s) {
+int vtd_launch_trocr_attention(const half_t* qkv, half_t* out, int n, int T, int C, int heads, int64_t out_prows, hipStream_t s) {
     if (heads * 64 != C || n <= 0 || T <= 0) return -2404;
     const int qtiles = (T + 127) / 128, units = heads * n;
     const int64_t grid = (int64_t)((units + 7) / 8) * 8 * qtiles;
-    hipLaunchKernelGGL(trocr_attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, T, C, 0.125f, heads, units, qtiles);
+    hipLaunchKernelGGL(trocr_attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, T, C, 0.125f, heads, units, qtiles, out_prows);
     return -(int)hipGetLastError();
 }

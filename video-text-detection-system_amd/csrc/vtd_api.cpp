@@ -105,6 +105,7 @@ struct ConvOp {
     TensorDesc in, out, res;
     bool has_res = false;
     half_t* w = nullptr;
+    half_t* w_panel = nullptr;   // the same weights K-panel-major, [K / 32][cout_pad][32] (dense_gemm.hip; dense layers of the Transformer encoder only)
     float* bias = nullptr;
     int k_hi_step = 32, cin_steps = 1, kw = 1, s_step = 0, r_step = 0;  // scalar K walk (ConvParams)
     int K = 0, cout = 0, cout_pad = 0, stride = 1, in_y0 = 0, in_x0 = 0, flags = 0, ps_cout = 0, res_shift = 0;
