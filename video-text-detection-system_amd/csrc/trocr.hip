@@ -10,6 +10,7 @@
 // (encoder self-attention: trocr_attention.hip; the decoder chain: trocr_decode.hip; the encoder pass's dense layers at whole-batch
 // token counts: dense_gemm.hip)
 #include <cmath>
+#include <cstdlib>
 #include "vtd_common.h"
 
 struct TrocrCrop {
@@ -150,10 +151,11 @@ __global__ __launch_bounds__(256) void trocr_ln_kernel(float* __restrict__ x, co
 // per operand instead of 12-16.  At the decoder's 272 rows the kernel is three dependent memory round trips whatever the row length;
 // fewer instructions in each is what is left to take.
 template <int MAXV4>
-__global__ __launch_bounds__(256) void trocr_ln4_kernel(float* __restrict__ x, const float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void trocr_ln4_kernel(float* __restrict__ x, const float* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, half_t* __restrict__ out16, float* __restrict__ out32,
                                                         int rows, int C, float eps, int mode, int64_t prows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // one wave per row; 4 waves per workgroup, 16 when the fp16 output is K-panel-major (16 consecutive rows = 1 KB contiguous per panel)
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     floatx4 v[MAXV4];
     const int nv = C / 256;
@@ -232,8 +234,11 @@ int vtd_launch_trocr_ln(float* x, const float* y, int ldy, const float* gamma, c
     const bool al = !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !(ldy & 3) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15) &&
                     !((uintptr_t)out16 & 7) && !((uintptr_t)out32 & 15);
     if (!(C & 255) && al) {
-        if (C <= 1024) hipLaunchKernelGGL(trocr_ln4_kernel<4>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
-        else hipLaunchKernelGGL(trocr_ln4_kernel<8>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
+        static const int wide = [] { const char* e = std::getenv("VTD_LN_PANEL_WAVES"); return e ? atoi(e) : 16; }();
+        const int waves = out16_prows ? (wide == 4 || wide == 8 || wide == 16 ? wide : 16) : 4;
+        const dim3 g4((rows + waves - 1) / waves), b4(64 * waves);
+        if (C <= 1024) hipLaunchKernelGGL(trocr_ln4_kernel<4>, g4, b4, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
+        else hipLaunchKernelGGL(trocr_ln4_kernel<8>, g4, b4, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
         return -(int)hipGetLastError();
     }
     if (C <= 1024) hipLaunchKernelGGL(trocr_ln_kernel<16>, grid, block, 0, s, x, y, ldy, gamma, beta, out16, out32, rows, C, eps, mode, out16_prows);
