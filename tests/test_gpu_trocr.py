@@ -481,3 +481,27 @@ def test_panel_major_gemm_inputs_change_no_bit(base, monkeypatch):
             e.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     assert float(np.abs(outs[0][0]).max()) > 0.1
+
+
+def test_tall_decoder_gemm_equals_the_small_one_bit_for_bit(hip, monkeypatch):
+    """From 768 live rows up the decoder's projections run on dec_gemm_tall_kernel (operands staged through LDS, 128 x 128 tiles on 16
+    waves); below, on dec_gemm_kernel (operands streamed into registers).  Both sum K in the same four quarters in the same order, so the
+    choice -- a function of the host's lagged row bound -- must not show in a single bit: 800 crops, teacher-forced logits of three steps
+    (every projection incl. the vocabulary's, split-K slabs, GELU) and greedy ids with either kernel."""
+    from vtd_amd.engine import TrOCREngine
+    sd = weights.trocr_state_dict(BASE_PRINTED, seed=0)
+    eng = TrOCREngine(BASE_PRINTED, sd, max_crops=800)
+    try:
+        g = torch.Generator().manual_seed(11)
+        base = torch.stack([otrocr.preprocess(synth.glyph_crop(1300 + i), BASE_PRINTED) for i in range(8)])
+        x = base[torch.arange(800) % 8] + 0.05 * torch.randn((800, 3, 384, 384), generator=g)
+        outs = []
+        for lds_from in ("768", "1000000"):
+            monkeypatch.setenv("VTD_DEC_GEMM_LDS", lds_from)
+            ids, lg = eng.generate_pixels(x, want_logits=True, max_length=4)
+            outs.append((ids.numpy().copy(), lg.numpy().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert np.array_equal(outs[0][1], outs[1][1])
+        assert float(np.abs(outs[0][1]).max()) > 1.0 and len({tuple(r) for r in outs[0][0].tolist()}) >= 4
+    finally:
+        eng.close()

@@ -19,6 +19,8 @@
 //    pinned host memory (read by the host two steps late as an upper bound for the launch geometry and as the stop test).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <cstdlib>
 #include "vtd_common.h"
 
 namespace {
@@ -129,6 +131,114 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmParams p) {
             }
         __syncthreads();
         for (int f = pass + w; f < pass + RF; f += 4) finish_fragment<MF, NF, RF>(p, red, f, pass, lane, fr, fq, m0, n0, rows);
+    }
+}
+
+// ---- the same GEMM for a TALL live list (thousands of rows: the first steps of a pass of many tickets).  dec_gemm_kernel streams its
+// operands from L2 straight into registers -- right for a few hundred rows, 140 TFLOP/s at 3264.  This one stages them through LDS:
+// 128 x 128 outputs per workgroup on 16 waves = 4 K-QUARTERS x (2 x 2 waves of 64 x 64).  The arithmetic is dec_gemm_kernel's, to the
+// bit: a wave group accumulates exactly the K quarter that wave `kq` of the small kernel accumulates (same 32-deep sub-steps, same order,
+// same MFMA operand roles), and the four quarters are summed 0 + 1 + 2 + 3 by the same finish_fragment -- so which of the two kernels ran,
+// a function of the host's lagged row bound, never shows in a result.
+constexpr int DT_BM = 128, DT_BN = 128;
+constexpr int DT_STAGE = 4 * (DT_BM + DT_BN) * 64;   // bytes per K-step of 32: four quarters x (A tile + W tile), 64-byte rows
+constexpr int DT_LDS = 2 * DT_STAGE;                  // 128 KB, double buffered; the quarter sums reuse it
+
+__device__ __forceinline__ int dt_key(int row) { return (0 - (row >> 2)) & 3; }   // chunk swizzle of a 64-byte row (as dense_gemm.hip: conflict-free
+                                                                                  // for the hardware's ds_read_b128 lane groups)
+
+__global__ __launch_bounds__(1024) void dec_gemm_tall_kernel(DecGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dt_smem[];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int kq = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
+    const int rows = min(*p.n_rows, p.M);
+    const int m0 = blockIdx.y * DT_BM, n0 = blockIdx.x * DT_BN;
+    const int kper = p.K / p.ksplit, nsub = kper >> 5;
+    // quarter q walks sub-steps [sub0(q), sub0(q + 1)) of the workgroup's K range, as wave q of dec_gemm_kernel does
+    const int n_pad = (p.N + 63) / 64 * 64;
+    int steps_max = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) steps_max = max(steps_max, ((nsub * (q + 1)) >> 2) - ((nsub * q) >> 2));
+    const int my_steps = ((nsub * (kq + 1)) >> 2) - ((nsub * kq) >> 2);
+
+    // loader: 4096 16-byte chunks per stage, four per thread: chunk id c = tid + 1024 j -> quarter c >> 10, then 512 A chunks (row, k-chunk) and
+    // 512 W chunks.  Rows past the bound re-read the last row (never stored); W rows past the padded N likewise.
+    const half_t* src[4];
+    int dst[4], lsteps[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 1024 * j, q = c >> 10, r = c & 1023, isw = r >> 9, row = (r & 511) >> 2, ch = r & 3;
+        const int sub0 = (nsub * q) >> 2;
+        lsteps[j] = ((nsub * (q + 1)) >> 2) - sub0;
+        const int kbeg = blockIdx.z * kper + (sub0 << 5) + ch * 8;
+        if (isw) {
+            int n = n0 + row;
+            n = n < n_pad ? n : n_pad - 1;
+            src[j] = p.W + (int64_t)n * p.K + kbeg;
+        } else {
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            src[j] = p.A + (int64_t)m * p.lda + kbeg;
+        }
+        dst[j] = q * ((DT_BM + DT_BN) * 64) + (isw ? DT_BM * 64 : 0) + row * 64 + ((ch ^ dt_key(row)) << 4);
+    }
+    half8 stg[4];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (s < lsteps[j]) stg[j] = *(const half8*)(src[j] + s * 32);
+    };
+    auto stage = [&](int s, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (s < lsteps[j]) *(half8*)(dt_smem + buf * DT_STAGE + dst[j]) = stg[j];
+    };
+    floatx4 acc[4][4];   // [m fragment][n fragment] of this wave's 64 x 64
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const char* const qbase = dt_smem + kq * ((DT_BM + DT_BN) * 64);
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+        a_off[i] = ra * 64 + ((fq ^ dt_key(ra)) << 4);
+        b_off[i] = DT_BM * 64 + rb * 64 + ((fq ^ dt_key(rb)) << 4);
+    }
+    fetch(0);
+    stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < steps_max; ++s) {
+        if (s + 1 < steps_max) fetch(s + 1);             // in flight under this step's maths
+        if (s < my_steps) {
+            const char* st = qbase + (s & 1) * DT_STAGE;
+            half8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { af[i] = *(const half8*)(st + a_off[i]); bf[i] = *(const half8*)(st + b_off[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < steps_max) stage(s + 1, (s + 1) & 1);   // the other buffer: last read in step s - 1, behind that step's barrier
+        __syncthreads();
+    }
+    // quarter sums through LDS (the staging buffers are free behind the last barrier): four fragments per pass; the four waves of a spatial
+    // position park theirs, then wave kq finishes fragment pass + kq with dec_gemm_kernel's own epilogue
+    float* const red = (float*)dt_smem + (wm * 2 + wn) * (4 * 4 * 256);   // [quarter][4 fragments][64 lanes][4]
+#pragma unroll
+    for (int pass = 0; pass < 16; pass += 4) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = i * 4 + j;
+                if (f >= pass && f < pass + 4) *(floatx4*)(red + ((kq * 4 + f - pass) * 64 + lane) * 4) = acc[i][j];
+            }
+        __syncthreads();
+        finish_fragment<4, 4, 4>(p, red, pass + kq, pass, lane, fr, fq, m0 + wm * 64, n0 + wn * 64, rows);
     }
 }
 
@@ -480,7 +590,16 @@ int vtd_launch_dec_gemm(const half_t* A, int lda, const half_t* W, const float* 
     if (ksplit > 1 && !(flags & DG_PARTIAL)) return -2502;
     DecGemmParams p{A, W, bias, out, slab_stride, n_rows_dev, lda, ldc, M, N, K, ksplit, flags};
     static const int tall = [] { const char* e = std::getenv("VTD_DEC_GEMM_TALL"); return e ? atoi(e) : 256; }();
-    if (wide || M >= tall) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile, and
+    int lds_from = 768;   // (read per launch: tests flip it inside one process; a getenv is nothing beside a launch)
+    if (const char* e = std::getenv("VTD_DEC_GEMM_LDS")) lds_from = atoi(e);
+    if (M >= lds_from && !(lda & 7) && !(K & 7)) {   // a tall live list: operands staged through LDS, same arithmetic (dec_gemm_tall_kernel)
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [] { attr = hipFuncSetAttribute((const void*)dec_gemm_tall_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS); });
+        if (attr != hipSuccess) return -(int)attr;
+        const dim3 grid((N + DT_BN - 1) / DT_BN, (M + DT_BM - 1) / DT_BM, ksplit);
+        hipLaunchKernelGGL(dec_gemm_tall_kernel, grid, dim3(1024), DT_LDS, s, p);
+    } else if (wide || M >= tall) {   // 64 x 64 tiles: the vocabulary projection (N ~ 50k), where the A tile is re-read by every column tile, and
         // any projection of a tall live list (half the operand re-reads of the 64 x 32 tile; same K order per output, same result)
         const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
         hipLaunchKernelGGL((dec_gemm_kernel<4, 4>), grid, dim3(256), 0, s, p);
