@@ -21,7 +21,7 @@ fn = getattr(lib, "_Z21vtd_launch_dense_gemmPKDF16_iS0_iPKfPvilii i P12ihipStrea
 if fn is None:
     import subprocess
     sym = [ln.split()[-1] for ln in subprocess.run(["nm", "-D", _native.LIB_PATH], capture_output=True, text=True).stdout.splitlines()
-           if "vtd_launch_dense_gemm" in ln][0]
+           if "vtd_launch_dense_gemm" in ln and "dense_gemm_ex" not in ln][0]
     fn = getattr(lib, sym)
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
